@@ -1,0 +1,207 @@
+"""Generate golden vectors by running the REAL reference code (read-only /root/reference).
+
+Run in the build container only:   python tests/golden/make_golden.py
+Outputs small ``tests/golden/*.npz`` fixtures (committed).  Each fixture holds: the seeded
+inputs, the reference ``state_dict`` before the step, the reference forward output, ClipLoss
+value, every parameter gradient, and the ``state_dict`` after ``n_steps`` of
+``zero_grad -> backward -> Adam.step`` (bm/solver.py:384-387 with the optimizer of
+bm/train.py:118-119).
+
+The reference has no golden vectors for this path; these fixtures are the pin
+for ``oracle/bm_oracle.py`` and, through it (and directly), for the HIP path.
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+
+from _ref_import import load_reference  # noqa: E402
+from brainmagick_amd.synthetic import make_batch  # noqa: E402
+
+SMALL = dict(C=20, T=48, F=10, S=5, B=6)
+
+# name -> (SimpleConv kwargs, hidden, training, extra)
+BASE = dict(depth=10, kernel_size=3, dilation_growth=2, dilation_period=5, batch_norm=True,
+            skip=True, gelu=True, glu=2, glu_context=1, glu_glu=True, complex_out=True,
+            merger=True, merger_pos_dim=32, merger_channels=12, merger_dropout=0.2,
+            initial_linear=12, initial_depth=1, subject_layers=True, subject_layers_dim="input",
+            subject_dim=0)
+
+
+def variant(**kw):
+    out = dict(BASE)
+    out.update(kw)
+    return out
+
+
+VARIANTS = {
+    # the paper model, scaled down; train mode with an injected ban centre; padded sensors
+    "clip_conv_train": dict(cfg=BASE, training=True, n_steps=2, n_layouts=2, pad_layout=True),
+    # eval mode: running BN stats, no sensor dropout
+    "clip_conv_eval": dict(cfg=BASE, training=False, n_steps=0, n_layouts=2, pad_layout=True),
+    # ablations from bm/grids/nmi/ablation_final.py:42-50
+    "no_merger_relu_noskip": dict(cfg=variant(merger=False, gelu=False, skip=False, glu=0,
+                                              initial_linear=0), training=True, n_steps=1),
+    "no_subject_layers_leaky": dict(cfg=variant(subject_layers=False, gelu=False,
+                                                relu_leakiness=0.1, merger_dropout=0.0),
+                                    training=True, n_steps=1),
+    "subject_embedding": dict(cfg=variant(subject_layers=False, subject_dim=8),
+                              training=True, n_steps=1),
+    "plain_out": dict(cfg=variant(complex_out=False), training=True, n_steps=1),
+    "linear_out_k5": dict(cfg=variant(complex_out=False, linear_out=True, kernel_size=5,
+                                      depth=4, dilation_period=None, glu=1, glu_context=0,
+                                      batch_norm=False),
+                          training=True, n_steps=1),
+    "initial_depth2_hidden_subject": dict(
+        cfg=variant(initial_depth=2, initial_nonlin=True, subject_layers_dim="hidden"),
+        training=True, n_steps=1),
+    "subsample_channels": dict(cfg=variant(subsample_meg_channels=9), training=True, n_steps=1),
+    # more candidates than estimates (negatives appended, bm/solver.py:359-371)
+    "extra_negatives": dict(cfg=BASE, training=True, n_steps=1, extra_negatives=7),
+}
+HIDDEN = 16
+
+
+class _Batch:
+    def __init__(self, sb):
+        self.meg = sb.meg
+        self.subject_index = sb.subject_index
+        self._recordings = sb._recordings
+        self._positions = sb.positions()
+
+    def __len__(self):
+        return len(self.meg)
+
+
+def run_variant(name, spec, sc, common, losses):
+    cfg = dict(spec["cfg"])
+    training = spec["training"]
+    seed = 2036 + sum(map(ord, name))
+    sb = make_batch(SMALL["B"], SMALL["C"], SMALL["T"], SMALL["F"], SMALL["S"], seed=seed,
+                    n_layouts=spec.get("n_layouts", 1))
+    if spec.get("pad_layout"):
+        # second recording has only 15 valid sensors (padded ones are INVALID / zero meg)
+        sb._recordings = [r if r.recording_index == 0 else
+                          type(r)(r.recording_index, r.layout[:15], r.study)
+                          for r in sb._recordings]
+        for i, r in enumerate(sb._recordings):
+            sb.meg[i, len(r.layout):] = 0
+    gen = torch.Generator().manual_seed(seed + 1)
+    n_neg = spec.get("extra_negatives", 0)
+    candidates = sb.features
+    if n_neg:
+        candidates = torch.cat([candidates, torch.randn(n_neg, SMALL["F"], SMALL["T"],
+                                                        generator=gen)])
+    ban_center = torch.rand(2, generator=gen)
+
+    torch.manual_seed(seed)
+    model = sc.SimpleConv(in_channels={"meg": SMALL["C"]}, out_channels=SMALL["F"],
+                          hidden={"meg": HIDDEN}, n_subjects=SMALL["S"], **cfg)
+    # non-trivial BN affine / running stats so that eval mode and BN grads are exercised
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.5, 1.5, generator=gen)
+                mod.bias.uniform_(-0.3, 0.3, generator=gen)
+                mod.running_mean.uniform_(-0.2, 0.2, generator=gen)
+                mod.running_var.uniform_(0.5, 1.5, generator=gen)
+    loss_mod = losses.ClipLoss()
+    optim = torch.optim.Adam(model.parameters(), lr=3e-4, betas=(0.9, 0.999))
+    model.train(training)
+    loss_mod.train(training)
+
+    batch = _Batch(sb)
+    common.PositionGetter.get_positions = lambda self, b: b._positions.clone()
+    real_rand = torch.rand
+
+    def fake_rand(*a, **k):          # bm/models/common.py:343 `torch.rand(2, device=...)`
+        if a == (2,):
+            return ban_center.clone()
+        return real_rand(*a, **k)
+
+    out = {"meta": json.dumps(dict(cfg=cfg, hidden=HIDDEN, training=training, **SMALL,
+                                   n_steps=spec["n_steps"], torch=torch.__version__))}
+    for k, v in model.state_dict().items():
+        out[f"sd0/{k}"] = v.detach().clone().numpy()
+    out["in/meg"] = sb.meg.numpy().copy()
+    out["in/positions"] = batch._positions.numpy().copy()
+    out["in/subjects"] = sb.subject_index.numpy().copy()
+    out["in/candidates"] = candidates.numpy().copy()
+    out["in/ban_center"] = ban_center.numpy().copy()
+
+    common.torch.rand = fake_rand
+    try:
+        losses_seen = []
+        steps = max(spec["n_steps"], 1)
+        for step in range(steps):
+            inputs = {"meg": sb.meg.clone()}
+            mask = torch.ones(len(sb.meg), 1, SMALL["T"], dtype=torch.bool)
+            if training and spec["n_steps"]:
+                estimate = model(inputs, batch)
+                loss = loss_mod(estimate, candidates, mask)
+                optim.zero_grad()
+                loss.backward()
+                if step == 0:
+                    out["out/estimate"] = estimate.detach().numpy().copy()
+                    for k, p in model.named_parameters():
+                        out[f"grad/{k}"] = p.grad.detach().numpy().copy()
+                optim.step()
+            else:
+                with torch.no_grad():
+                    estimate = model(inputs, batch)
+                    loss = loss_mod(estimate, candidates, mask)
+                    out["out/estimate"] = estimate.numpy().copy()
+                    out["out/probabilities"] = loss_mod.get_probabilities(
+                        estimate, candidates).numpy().copy()
+            losses_seen.append(float(loss))
+    finally:
+        common.torch.rand = real_rand
+    out["out/losses"] = np.asarray(losses_seen, dtype=np.float64)
+    for k, v in model.state_dict().items():
+        out[f"sd1/{k}"] = v.detach().clone().numpy()
+    return out
+
+
+def clip_only_fixture(losses):
+    """ClipLoss options (pool / center / trim) on their own, incl. B' > B."""
+    gen = torch.Generator().manual_seed(77)
+    est = torch.randn(5, 7, 33, generator=gen)
+    cand = torch.randn(9, 7, 33, generator=gen) * 3 + 0.5
+    out = {"in/estimate": est.numpy().copy(), "in/candidate": cand.numpy().copy()}
+
+    class DsetArgs:
+        tmin = -0.5
+        sample_rate = 20
+
+    for tag, kw in [("plain", {}), ("pool", dict(pool=True)), ("center", dict(center=True)),
+                    ("trim", dict(tmin=-0.2, tmax=0.9, dset_args=DsetArgs()))]:
+        mod = losses.ClipLoss(**kw)
+        mod.eval()
+        e = est.clone().requires_grad_(True)
+        loss = mod(e, cand, torch.ones(5, 1, 33, dtype=torch.bool))
+        loss.backward()
+        out[f"{tag}/scores"] = mod.get_scores(est, cand).numpy().copy()
+        out[f"{tag}/probabilities"] = mod.get_probabilities(est, cand).numpy().copy()
+        out[f"{tag}/loss"] = np.asarray(float(loss))
+        out[f"{tag}/grad_estimate"] = e.grad.numpy().copy()
+    return out
+
+
+def main():
+    sc, common, losses = load_reference()
+    for name, spec in VARIANTS.items():
+        out = run_variant(name, spec, sc, common, losses)
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(f"{name}: losses={out['out/losses']}")
+    np.savez_compressed(HERE / "clip_loss.npz", **clip_only_fixture(losses))
+    print("clip_loss: done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""oracle/bm_oracle.py vs golden vectors produced by the live reference (CPU only)."""
+import pytest
+import torch
+
+from oracle import bm_oracle as O
+from helpers import Golden, MODEL_FIXTURES, rel_l2
+
+# fp32 oracle vs fp32 reference: same torch kernels in (nearly) the same order
+FWD_TOL = 2e-6
+GRAD_TOL = 2e-5
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_oracle_matches_reference(name):
+    g = Golden(name)
+    meta = g.meta
+    sd0, sd1, grads = g.group("sd0"), g.group("sd1"), g.group("grad")
+    inp = g.group("in")
+    model = O.OracleModel(sd0, meta["cfg"], meta["hidden"], meta["F"])
+    training = meta["training"]
+    if training and meta["n_steps"]:
+        losses = []
+        for step in range(meta["n_steps"]):
+            loss, est, gr = model.train_step(inp["meg"], inp["positions"], inp["subjects"],
+                                             inp["candidates"], inp["ban_center"])
+            losses.append(float(loss))
+            if step == 0:
+                assert rel_l2(est, g.t("out/estimate")) < FWD_TOL
+                assert set(gr) == set(grads)
+                for k in grads:
+                    assert rel_l2(gr[k], grads[k]) < GRAD_TOL, k
+        ref_losses = g.raw["out/losses"]
+        assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 1e-5
+        for k, v in sd1.items():
+            if v.is_floating_point():
+                assert rel_l2(model.sd[k], v) < 1e-5, k
+            else:
+                assert int(model.sd[k]) == int(v), k
+    else:
+        est = model.forward(inp["meg"], inp["positions"], inp["subjects"], training=False)
+        assert rel_l2(est, g.t("out/estimate")) < FWD_TOL
+        loss = O.clip_loss(est, inp["candidates"])
+        assert abs(float(loss) - g.raw["out/losses"][0]) < 1e-5
+        probs = O.clip_probabilities(est, inp["candidates"])
+        assert rel_l2(probs, g.t("out/probabilities")) < 1e-5
+
+
+def test_oracle_fp64_close_to_fp32_reference():
+    g = Golden("clip_conv_eval")
+    model = O.OracleModel(g.group("sd0"), g.meta["cfg"], g.meta["hidden"], g.meta["F"],
+                          dtype=torch.float64)
+    inp = g.group("in")
+    est = model.forward(inp["meg"], inp["positions"], inp["subjects"])
+    assert rel_l2(est, g.t("out/estimate")) < 1e-5
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}), ("pool", dict(pool=True)),
+                                    ("center", dict(center=True)), ("trim", None)])
+def test_clip_loss_options(tag, kw):
+    g = Golden("clip_loss")
+    est, cand = g.t("in/estimate").requires_grad_(True), g.t("in/candidate")
+    e, c = est, cand
+    if kw is None:
+        e, c = O.clip_trim(est, cand, tmin=-0.2, tmax=0.9, dset_tmin=-0.5, sample_rate=20)
+        kw = {}
+    scores = O.clip_scores(e, c, **kw)
+    assert rel_l2(scores, g.t(f"{tag}/scores")) < 1e-6
+    loss = O.clip_loss(e, c, **kw)
+    assert abs(float(loss) - float(g.raw[f"{tag}/loss"])) < 1e-6
+    loss.backward()
+    assert rel_l2(est.grad, g.t(f"{tag}/grad_estimate")) < 1e-5
+    assert rel_l2(O.clip_probabilities(e, c, **kw), g.t(f"{tag}/probabilities")) < 1e-6
+
+
+def test_invalid_sensors_have_no_influence():
+    """INVALID-position sensors carry exactly zero attention weight."""
+    g = Golden("clip_conv_eval")
+    inp = g.group("in")
+    model = O.OracleModel(g.group("sd0"), g.meta["cfg"], g.meta["hidden"], g.meta["F"])
+    base = model.forward(inp["meg"], inp["positions"], inp["subjects"])
+    meg = inp["meg"].clone()
+    invalid = O.is_invalid(inp["positions"])
+    assert invalid.any()
+    meg[invalid] = 123.0
+    assert torch.equal(model.forward(meg, inp["positions"], inp["subjects"]), base)
+
+
+def test_topk_accuracy_rule():
+    probs = torch.tensor([[0.1, 0.7, 0.2], [0.5, 0.3, 0.2], [0.2, 0.3, 0.5]])
+    labels = torch.tensor([0, 1, 2])
+    assert O.topk_accuracy(probs, labels, labels, topk=1) == pytest.approx(1 / 3)
+    assert O.topk_accuracy(probs, labels, labels, topk=2) == pytest.approx(2 / 3)
