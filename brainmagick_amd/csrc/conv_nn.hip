@@ -1,0 +1,245 @@
+// Implicit-GEMM 1-D convolution ("NN" form: weights x activations, time contiguous) on the CDNA4
+// matrix cores with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   y[b][m][t] = ep( bias[m] + sum_{c,j} W[g(b)][m][c][j] * x[b][c][t + (j - KS/2)*dil] )
+//
+// One kernel covers every "weights x [C,T] window" contraction of the SimpleConv hot path:
+//   * nn.Conv1d k=3 dilated "same" convs of ConvSequence        (bm/models/common.py:113-114)
+//   * the GLU convs and all 1x1 convs / ConvTranspose1d(k=1)     (common.py:133-138, simpleconv.py:113-120,185-189)
+//   * SubjectLayers' per-subject matmul (weight picked by widx)  (common.py:55-58)
+//   * ChannelMerger's weighted sensor reduction                  (common.py:358)
+//   * every data-gradient of the above (weights packed transposed+flipped by pack.hip)
+//   * ClipLoss' dEstimate = dScores x candidates                  (losses.py:94, backward)
+//
+// Tiling (MI355X-first, wave64): a workgroup is 4 wavefronts and owns a [BM = 32*MT] x [BN = 128]
+// output tile of ONE segment b; wavefront w owns the 32-column strip w and all MT 32-row blocks
+// (MT f32x16 accumulators, 1 B-operand + MT A-operand ds_read_b32 per MT MFMAs).  The input
+// window x[b][c0:c0+16][n0-halo : n0+128+halo] is staged ONCE in LDS and re-used by all KS taps
+// (the taps are just column offsets j*dil into the same LDS rows), weights arrive pre-packed as
+// [chunk][tap][16 channels][Mpad] so that the A tile is a straight, 16-byte-vectorised copy and
+// both MFMA operands are conflict-free consecutive-lane LDS reads.
+#include "bm_common.h"
+
+struct ConvNNArgs {
+    const float* x;       long x_bstride;      // [B][Cin][T]
+    const float* wp;                           // packed [G][nchunk][KS][BKC][Mpad]
+    const int* widx;                           // [B] weight-group per segment, or null (group 0)
+    const float* bias;                         // [M] or null
+    const float* ep_scale; const float* ep_shift;   // [M] per-channel affine applied before act, or null
+    const float* res;     long res_bstride;    // residual added after act, or null
+    float* y_pre;                              // pre-activation output (after bias), or null
+    float* y_out;                              // post-epilogue output, or null
+    long y_bstride;
+    float* stats;                              // [B*NTILES][M][2] per-tile (sum, sumsq) of y_pre, or null
+    int B, Cin, M, T, KS, dil, Mpad, nchunk, act;
+    float leak;
+    int ntiles_n, ntiles_m;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void conv_nn_kernel(ConvNNArgs a) {
+    constexpr int BM = 32 * MT;
+    constexpr int BN = 128;
+    constexpr int BKC = BM_BKC;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nl = lane & 31;
+    const int h = lane >> 5;
+
+    // logical block id -> (b, ntile, mtile); mtile fastest so that blocks sharing an x window
+    // are neighbours on the same XCD.
+    const int nblocks = gridDim.x;
+    int id = bm_xcd_remap(blockIdx.x, nblocks);
+    const int mtile = id % a.ntiles_m;
+    id /= a.ntiles_m;
+    const int ntile = id % a.ntiles_n;
+    const int b = id / a.ntiles_n;
+
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+    const int halo = (a.KS >> 1) * a.dil;
+    const int XW = BN + 2 * halo;          // staged window width
+    const int KSB = a.KS * BKC;            // packed rows per chunk
+    float* As = smem;                      // [KSB][BM]
+    float* Xs = smem + KSB * BM;           // [BKC][XW]
+
+    const int g = a.widx ? a.widx[b] : 0;
+    const float* xb = a.x + (long)b * a.x_bstride;
+    const float* wg = a.wp + (long)g * a.nchunk * KSB * a.Mpad + m0;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        // ---- stage A: KSB rows of BM floats (float4 copies, rows are Mpad-strided) ----
+        const float* wsrc = wg + (long)chunk * KSB * a.Mpad;
+        constexpr int Q = BM / 4;
+        for (int e = tid; e < KSB * Q; e += 256) {
+            const int r = e / Q, q = e - r * Q;
+            const float4 v = *reinterpret_cast<const float4*>(wsrc + (long)r * a.Mpad + q * 4);
+            *reinterpret_cast<float4*>(As + r * BM + q * 4) = v;
+        }
+        // ---- stage X window: BKC rows of XW floats, zero outside [0,T) x [0,Cin) ----
+        const int c0 = chunk * BKC;
+        for (int cc = wave; cc < BKC; cc += 4) {
+            const int c = c0 + cc;
+            const float* xr = xb + (long)c * a.T;
+            for (int xx = lane; xx < XW; xx += 64) {
+                const int t = n0 - halo + xx;
+                float v = 0.f;
+                if (c < a.Cin && t >= 0 && t < a.T) v = xr[t];
+                Xs[cc * XW + xx] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: k runs over (tap j, channel pair p); lanes 0-31 feed k even, 32-63 k odd ----
+        for (int j = 0; j < a.KS; ++j) {
+            const float* xrow = Xs + h * XW + wave * 32 + nl + j * a.dil;
+            const float* arow = As + (j * BKC + h) * BM + nl;
+#pragma unroll
+            for (int p = 0; p < BKC / 2; ++p) {
+                const float bv = xrow[2 * p * XW];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float av = arow[2 * p * BM + mt * 32];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    const int col = n0 + wave * 32 + nl;
+    const bool col_ok = col < a.T;
+    float* red = smem;   // [4 waves][BM][2] for the BatchNorm partial statistics (LDS is free now)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = m0 + rl;
+            const bool ok = col_ok && row < a.M;
+            float v = acc[mt][r];
+            if (a.bias && row < a.M) v += a.bias[row];
+            const long off = (long)row * a.T + col;
+            if (a.y_pre && ok) a.y_pre[(long)b * a.y_bstride + off] = v;
+            if (a.stats) {
+                float s = ok ? v : 0.f;
+                float s2 = s * s;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    s += __shfl_xor(s, o);
+                    s2 += __shfl_xor(s2, o);
+                }
+                if (nl == 0) {
+                    red[(wave * BM + rl) * 2 + 0] = s;
+                    red[(wave * BM + rl) * 2 + 1] = s2;
+                }
+            }
+            if (a.y_out && ok) {
+                float z = v;
+                if (a.ep_scale) z = z * a.ep_scale[row] + a.ep_shift[row];
+                z = bm_act(z, a.act, a.leak);
+                if (a.res) z += a.res[(long)b * a.res_bstride + off];
+                a.y_out[(long)b * a.y_bstride + off] = z;
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        for (int rl = tid; rl < BM; rl += 256) {
+            const int row = m0 + rl;
+            if (row < a.M) {
+                float s = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s += red[(w * BM + rl) * 2 + 0];
+                    s2 += red[(w * BM + rl) * 2 + 1];
+                }
+                float* dst = a.stats + ((long)(b * a.ntiles_n + ntile) * a.M + row) * 2;
+                dst[0] = s;
+                dst[1] = s2;
+            }
+        }
+    }
+}
+
+template <int MT>
+static int launch_conv_nn(const ConvNNArgs& a, hipStream_t stream) {
+    constexpr int BM = 32 * MT;
+    const int halo = (a.KS >> 1) * a.dil;
+    const int XW = 128 + 2 * halo;
+    size_t lds = (size_t)(a.KS * BM_BKC * BM + BM_BKC * XW) * sizeof(float);
+    const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+    if (lds < lds_red) lds = lds_red;
+    if (lds > 160 * 1024) return bm_set_error(BM_ERR_UNSUPPORTED, "conv_nn: LDS tile %zu B too large (KS=%d dil=%d)", lds, a.KS, a.dil);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_kernel<MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return bm_set_error((int)e, "conv_nn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const long nblocks = (long)a.B * a.ntiles_n * a.ntiles_m;
+    if (nblocks <= 0) return BM_OK;
+    hipLaunchKernelGGL(conv_nn_kernel<MT>, dim3((unsigned)nblocks), dim3(256), lds, stream, a);
+    return bm_check_launch("conv_nn");
+}
+
+// Row-tile height (in 32-row MFMA blocks) that minimises padded rows for M output channels.
+extern "C" int bm_conv_mt_for(int M) {
+    int best = 1;
+    long best_cost = -1;
+    for (int mt = 1; mt <= 5; ++mt) {
+        const long bm = 32L * mt;
+        const long padded = (long)cdiv(M, bm) * bm;
+        // prefer less padding; among equals prefer the taller tile (fewer x re-reads)
+        const long cost = padded * 16 - mt;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt; }
+    }
+    return best;
+}
+
+extern "C" int bm_conv_mpad(int M) {
+    const int mt = bm_conv_mt_for(M);
+    return cdiv(M, 32 * mt) * 32 * mt;
+}
+
+extern "C" int bm_conv_stats_tiles(int B, int T) { return B * cdiv(T, 128); }
+
+// C-ABI: replaces F.conv1d / einsum call sites listed in the header comment.
+extern "C" int bm_conv1d_nn(const float* x, long x_bstride, const float* wpacked, const int* widx,
+                            const float* bias, const float* ep_scale, const float* ep_shift,
+                            const float* res, long res_bstride, float* y_pre, float* y_out,
+                            long y_bstride, float* stats, int B, int Cin, int M, int T, int KS,
+                            int dil, int act, float leak, void* stream) {
+    BM_REQUIRE(x && wpacked, "conv1d_nn: null x/w");
+    BM_REQUIRE(y_pre || y_out, "conv1d_nn: no output");
+    BM_REQUIRE(KS >= 1 && (KS & 1), "conv1d_nn: kernel size must be odd (got %d)", KS);
+    BM_REQUIRE(B >= 0 && Cin > 0 && M > 0 && T > 0 && dil >= 1, "conv1d_nn: bad dims");
+    BM_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv1d_nn: scale/shift must come together");
+    ConvNNArgs a;
+    a.x = x; a.x_bstride = x_bstride; a.wp = wpacked; a.widx = widx; a.bias = bias;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
+    a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = stats;
+    a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;
+    const int mt = bm_conv_mt_for(M);
+    a.Mpad = bm_conv_mpad(M);
+    a.nchunk = cdiv(Cin, BM_BKC);
+    a.ntiles_n = cdiv(T, 128);
+    a.ntiles_m = a.Mpad / (32 * mt);
+    hipStream_t s = (hipStream_t)stream;
+    switch (mt) {
+        case 1: return launch_conv_nn<1>(a, s);
+        case 2: return launch_conv_nn<2>(a, s);
+        case 3: return launch_conv_nn<3>(a, s);
+        case 4: return launch_conv_nn<4>(a, s);
+        default: return launch_conv_nn<5>(a, s);
+    }
+}

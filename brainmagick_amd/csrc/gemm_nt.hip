@@ -1,0 +1,210 @@
+// "NT" contraction over time with optional tap shifts, on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//
+//   part[g, split][m][c*KS + j] = sum_{s in group g (split's share)} sum_t
+//                                   A[s][m][t] * X[s][c][t + (j - KS/2)*dil]      (zero outside [0,T))
+//
+// Both operands are time-contiguous, the reduction runs over (segment, time).  It covers:
+//   * conv weight gradients  dW[o][c][j] = sum_{b,t} dY[b][o][t] x[b][c][t+shift]   (autograd of common.py:113-114)
+//   * per-subject / per-layout grouped weight gradients (SubjectLayers, ChannelMerger; groups via order/seg)
+//   * ClipLoss scores  est[B][F*T] . cand[B'][F*T]^T                               (bm/losses.py:94)
+//   * ChannelMerger logits heads[O][D] . emb[u][C][D]^T                            (bm/models/common.py:355)
+//
+// Tiling: a workgroup is WM x WC wavefronts; wavefront (wm, wc) owns MT x NT 32x32 MFMA blocks for
+// each of the KS taps.  A rows and X rows are staged in LDS with an odd pitch (conflict-free
+// row-per-lane ds_read_b32); the X window carries a +-halo so all taps read the same LDS rows.
+// The reduction domain is a flat list of (segment, 32-sample time chunk) pairs; `nsplit` workgroups
+// share one output tile (split-K) and write separate partial tiles that pack.hip's
+// bm_reduce_splits folds in a fixed order (deterministic).
+#include "bm_common.h"
+
+#define BKT 32
+
+struct GemmNTArgs {
+    const float* a; long a_sstride; long a_rstride;   // A[s][m][t]
+    const float* x; long x_sstride; long x_rstride;   // X[s][c][t]
+    const int* order;                                  // segment list (grouped) or null = identity
+    const int* seg;                                    // [G+1] group boundaries or null = one group [0, S)
+    float* part;                                       // [G*nsplit][M][Cn*KS]
+    int S, M, Cn, T, dil, nsplit, G;
+    int tiles_m, tiles_c;
+};
+
+template <int WM, int WC, int MT, int NT, int KS>
+__global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
+    constexpr int NW = WM * WC;
+    constexpr int NTH = NW * 64;
+    constexpr int BM = WM * MT * 32;
+    constexpr int BC = WC * NT * 32;
+    constexpr int PA = BKT + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WC, wc = wave % WC;
+    const int nl = lane & 31, h = lane >> 5;
+
+    const int halo = (KS >> 1) * a.dil;
+    const int XW = BKT + 2 * halo;
+    const int PX = XW | 1;                     // odd pitch
+    float* As = smem;                          // [BM][PA]
+    float* Xs = smem + BM * PA;                // [BC][PX]
+
+    // block -> (tile_m, tile_c, split, g)
+    int id = blockIdx.x;
+    const int tm = id % a.tiles_m; id /= a.tiles_m;
+    const int tc = id % a.tiles_c; id /= a.tiles_c;
+    const int split = id % a.nsplit;
+    const int g = id / a.nsplit;
+    const int m0 = tm * BM, c0 = tc * BC;
+
+    const int s_begin = a.seg ? a.seg[g] : 0;
+    const int s_end = a.seg ? a.seg[g + 1] : a.S;
+    const int cps = (a.T + BKT - 1) / BKT;                     // chunks per segment
+    const long nchunks = (long)(s_end - s_begin) * cps;
+    const long q_begin = nchunks * split / a.nsplit;
+    const long q_end = nchunks * (split + 1) / a.nsplit;
+
+    f32x16 acc[MT][NT][KS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][k][j][r] = 0.f;
+
+    for (long q = q_begin; q < q_end; ++q) {
+        const int sl = (int)(q / cps);
+        const int t0 = (int)(q - (long)sl * cps) * BKT;
+        int s = s_begin + sl;
+        if (a.order) s = a.order[s];
+        const float* ab = a.a + (long)s * a.a_sstride;
+        const float* xb = a.x + (long)s * a.x_sstride;
+        // stage A rows: half-wave per row, 32 consecutive floats
+        for (int i = tid >> 5; i < BM; i += NTH / 32) {
+            const int m = m0 + i, t = t0 + (tid & 31);
+            float v = 0.f;
+            if (m < a.M && t < a.T) v = ab[(long)m * a.a_rstride + t];
+            As[i * PA + (tid & 31)] = v;
+        }
+        // stage X rows with halo
+        for (int i = wave; i < BC; i += NW) {
+            const int c = c0 + i;
+            const float* xr = xb + (long)c * a.x_rstride;
+            for (int xx = lane; xx < XW; xx += 64) {
+                const int t = t0 - halo + xx;
+                float v = 0.f;
+                if (c < a.Cn && t >= 0 && t < a.T) v = xr[t];
+                Xs[i * PX + xx] = v;
+            }
+        }
+        __syncthreads();
+        const int tvalid = min(BKT, a.T - t0);
+        const int ksteps = (tvalid + 1) >> 1;
+        const float* ap = As + (wm * MT * 32 + nl) * PA + h;
+        const float* xp = Xs + (wc * NT * 32 + nl) * PX + h;
+        for (int kk = 0; kk < ksteps; ++kk) {
+            float av[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = ap[i * 32 * PA + 2 * kk];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const float bv = xp[k * 32 * PX + 2 * kk + j * a.dil];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][k][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][k][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: part[(g*nsplit+split)][m][c*KS + j]
+    const long N = (long)a.Cn * KS;
+    float* dst = a.part + (long)(g * a.nsplit + split) * a.M * N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int c = c0 + wc * NT * 32 + k * 32 + nl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.M && c < a.Cn) {
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) dst[(long)m * N + (long)c * KS + j] = acc[i][k][j][r];
+                }
+            }
+        }
+}
+
+template <int WM, int WC, int MT, int NT, int KS>
+static int launch_gemm_nt(GemmNTArgs a, hipStream_t stream) {
+    constexpr int BM = WM * MT * 32, BC = WC * NT * 32;
+    const int halo = (KS >> 1) * a.dil;
+    const int PX = (BKT + 2 * halo) | 1;
+    const size_t lds = (size_t)(BM * (BKT + 1) + BC * PX) * sizeof(float);
+    if (lds > 160 * 1024) return bm_set_error(BM_ERR_UNSUPPORTED, "gemm_nt: LDS tile too large (dil=%d)", a.dil);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<WM, WC, MT, NT, KS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_c = cdiv(a.Cn, BC);
+    const long nblocks = (long)a.tiles_m * a.tiles_c * a.nsplit * a.G;
+    if (nblocks <= 0) return BM_OK;
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WC, MT, NT, KS>), dim3((unsigned)nblocks), dim3(WM * WC * 64),
+                       lds, stream, a);
+    return bm_check_launch("gemm_nt");
+}
+
+// Picks the tile (128 or 64 rows / cols) with the least padding.
+static inline bool prefer_big(int n) { return (long)cdiv(n, 128) * 128 <= (long)cdiv(n, 64) * 64; }
+
+// Suggested split count so that the launch has ~>= 4 workgroups per CU.
+extern "C" int bm_gemm_nt_suggest_splits(int M, int Cn, int KS, int S, int T, int G) {
+    int tiles;
+    if (KS == 1) tiles = cdiv(M, prefer_big(M) ? 128 : 64) * cdiv(Cn, prefer_big(Cn) ? 128 : 64);
+    else tiles = cdiv(M, prefer_big(M) ? 128 : 64) * cdiv(Cn, 64);
+    long chunks = (long)S * cdiv(T, BKT);
+    if (G > 1) return 1;
+    long want = (1024 + tiles - 1) / tiles;
+    if (want > chunks / 8) want = chunks / 8;     // keep >= 8 chunks of work per workgroup
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    return (int)want;
+}
+
+extern "C" int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x,
+                          long x_sstride, long x_rstride, const int* order, const int* seg,
+                          float* part, int S, int G, int M, int Cn, int T, int KS, int dil,
+                          int nsplit, void* stream) {
+    BM_REQUIRE(a && x && part, "gemm_nt: null pointer");
+    BM_REQUIRE(M > 0 && Cn > 0 && T > 0 && G > 0 && nsplit > 0 && S >= 0, "gemm_nt: bad dims");
+    BM_REQUIRE(G == 1 || seg, "gemm_nt: grouped call needs seg[]");
+    GemmNTArgs g;
+    g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride;
+    g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride;
+    g.order = order; g.seg = seg; g.part = part;
+    g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit; g.G = G;
+    hipStream_t s = (hipStream_t)stream;
+    const bool bigM = prefer_big(M);
+    if (KS == 1) {
+        const bool bigC = prefer_big(Cn);
+        if (bigM && bigC) return launch_gemm_nt<2, 2, 2, 2, 1>(g, s);
+        if (bigM) return launch_gemm_nt<2, 2, 2, 1, 1>(g, s);
+        if (bigC) return launch_gemm_nt<2, 2, 1, 2, 1>(g, s);
+        return launch_gemm_nt<2, 2, 1, 1, 1>(g, s);
+    }
+    if (KS == 3) {
+        if (bigM) return launch_gemm_nt<2, 2, 2, 1, 3>(g, s);
+        return launch_gemm_nt<2, 2, 1, 1, 3>(g, s);
+    }
+    if (KS == 5) return launch_gemm_nt<2, 2, 1, 1, 5>(g, s);
+    return bm_set_error(BM_ERR_UNSUPPORTED, "gemm_nt: kernel size %d not supported (1, 3, 5)", KS);
+}

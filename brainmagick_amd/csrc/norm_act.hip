@@ -1,0 +1,458 @@
+// HBM-bound epilogue kernels of the ConvSequence block (bm/models/common.py:113-151):
+// BatchNorm1d (train: batch statistics over (B,T); eval: running statistics), GELU/ReLU/LeakyReLU,
+// residual add, GLU -- forward and backward.  All tensors are fp32 [B][C][T] with T contiguous;
+// every kernel streams rows with 16-byte accesses when T % 4 == 0 (the 360-sample case) and falls
+// back to dword accesses otherwise (T = 343 / 361 ...).  Channel reductions are two-stage
+// (per-(channel, split) partials in a fixed order -> deterministic).
+#include "bm_common.h"
+
+template <int VEC> struct Pack;
+template <> struct Pack<1> {
+    float v[1];
+    __device__ static Pack ld(const float* p) { Pack r; r.v[0] = *p; return r; }
+    __device__ void st(float* p) const { *p = v[0]; }
+};
+template <> struct Pack<4> {
+    float v[4];
+    __device__ static Pack ld(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        Pack r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+    }
+    __device__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+// Block reduction of NV doubles (sum); result valid in thread 0.
+template <int NV>
+__device__ void block_sum(double (&v)[NV], double* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = bm_wave_sum_d(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sh[wave * NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0;
+            for (int w = 0; w < nw; ++w) s += sh[w * NV + i];
+            v[i] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics: fold the per-tile (sum, sumsq) partials written by conv_nn's epilogue.
+// torch semantics: normalise with the biased variance, update running_var with the unbiased one,
+// running = (1 - momentum) * running + momentum * batch, num_batches_tracked += 1.
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, long* num_batches,
+                                   float momentum, float eps, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                   float* __restrict__ shift_out) {
+    const int c = blockIdx.x;
+    double s = 0, s2 = 0;
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        s += (double)stats[((long)t * C + c) * 2 + 0];
+        s2 += (double)stats[((long)t * C + c) * 2 + 1];
+    }
+    s = bm_wave_sum_d(s);
+    s2 = bm_wave_sum_d(s2);
+    if (threadIdx.x == 0) {
+        const double mean = s / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        scale_out[c] = sc;
+        shift_out[c] = bt - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1 ? var * count / (count - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        if (num_batches && c == 0) *num_batches += 1;
+    }
+}
+
+extern "C" int bm_bn_finalize(const float* stats, int ntiles, int C, long count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              long* num_batches, float momentum, float eps, float* mean,
+                              float* invstd, float* scale, float* shift, void* stream) {
+    BM_REQUIRE(stats && mean && invstd && scale && shift, "bn_finalize: null pointer");
+    BM_REQUIRE(C > 0 && ntiles > 0 && count > 0, "bn_finalize: bad dims");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, ntiles, C,
+                       (double)count, gamma, beta, running_mean, running_var, num_batches, momentum,
+                       eps, mean, invstd, scale, shift);
+    return bm_check_launch("bn_finalize");
+}
+
+// eval mode: scale/shift from the running statistics.
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta,
+                                      const float* running_mean, const float* running_var,
+                                      float eps, float* mean, float* invstd, float* scale,
+                                      float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    mean[c] = running_mean[c];
+    invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - running_mean[c] * sc;
+}
+
+extern "C" int bm_bn_eval_affine(int C, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, float eps,
+                                 float* mean, float* invstd, float* scale, float* shift,
+                                 void* stream) {
+    BM_REQUIRE(running_mean && running_var && scale && shift, "bn_eval_affine: null pointer");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C,
+                       gamma, beta, running_mean, running_var, eps, mean, invstd, scale, shift);
+    return bm_check_launch("bn_eval_affine");
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: out = act(y * scale[c] + shift[c]) + res
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void affine_act_res_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, const float* __restrict__ res,
+                                      float* __restrict__ out, long nvec, int C, int T, int act,
+                                      float leak) {
+    const int TV = T / VEC;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec;
+         e += (long)gridDim.x * blockDim.x) {
+        const long row = e / TV;
+        const int c = (int)(row % C);
+        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        Pack<VEC> v = Pack<VEC>::ld(y + e * VEC);
+        Pack<VEC> r;
+        if (res) r = Pack<VEC>::ld(res + e * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float z = bm_act(v.v[i] * sc + sh, act, leak);
+            if (res) z += r.v[i];
+            v.v[i] = z;
+        }
+        v.st(out + e * VEC);
+    }
+}
+
+extern "C" int bm_affine_act_res(const float* y, const float* scale, const float* shift,
+                                 const float* res, float* out, int B, int C, int T, int act,
+                                 float leak, void* stream) {
+    BM_REQUIRE(y && out, "affine_act_res: null pointer");
+    const long n = (long)B * C * T;
+    if (n == 0) return BM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (T % 4 == 0) {
+        const long nvec = n / 4;
+        const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
+        hipLaunchKernelGGL(affine_act_res_kernel<4>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
+                           out, nvec, C, T, act, leak);
+    } else {
+        const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+        hipLaunchKernelGGL(affine_act_res_kernel<1>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
+                           out, n, C, T, act, leak);
+    }
+    return bm_check_launch("affine_act_res");
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of  out = act(bn(y)) [+ res]
+//   dz = dout * act'(z),  z = y*scale + shift
+//   train BN:  dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat)),  dgamma = sum dz*xhat, dbeta = sum dz
+//   eval BN:   dy = scale * dz ;  no BN:  dy = dz
+// Pass 1 (bn_bwd_reduce): per-(channel, split) partial sums.  Pass 2 (bn_bwd_apply): dy + sum(dy).
+// ------------------------------------------------------------------------------------------------
+#define NSPLIT_MAX 32
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    double* __restrict__ partial, int B, int C, int T, int act, float leak) {
+    __shared__ double sh[4 * 2];
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const int TV = T / VEC;
+    const float sc = scale ? scale[c] : 1.f, shf = scale ? shift[c] : 0.f;
+    const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
+    double acc[2] = {0, 0};
+    float s0 = 0.f, s1 = 0.f;
+    const long nloc = (long)(b1 - b0) * TV;
+    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
+        const int bl = (int)(e / TV);
+        const int tv = (int)(e - (long)bl * TV);
+        const long off = ((long)(b0 + bl) * C + c) * T + (long)tv * VEC;
+        const Pack<VEC> d = Pack<VEC>::ld(dout + off), v = Pack<VEC>::ld(y + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float dz = d.v[i] * bm_act_grad(v.v[i] * sc + shf, act, leak);
+            s0 += dz;
+            s1 += dz * ((v.v[i] - mu) * is);
+        }
+    }
+    acc[0] = s0; acc[1] = s1;
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) {
+        partial[((long)c * nsplit + split) * 2 + 0] = acc[0];
+        partial[((long)c * nsplit + split) * 2 + 1] = acc[1];
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const double* __restrict__ partial, int bn_train, float* __restrict__ dy,
+    double* __restrict__ dy_partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
+    int C, int T, int act, float leak) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const int TV = T / VEC;
+    const float sc = scale ? scale[c] : 1.f, shf = scale ? shift[c] : 0.f;
+    const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
+    float k1 = 0.f, k2 = 0.f;
+    if (bn_train) {
+        double sdz = 0, sdzx = 0;
+        for (int k = 0; k < nsplit; ++k) {
+            sdz += partial[((long)c * nsplit + k) * 2 + 0];
+            sdzx += partial[((long)c * nsplit + k) * 2 + 1];
+        }
+        const double n = (double)B * T;
+        k1 = (float)(sdz / n);
+        k2 = (float)(sdzx / n);
+        if (split == 0 && threadIdx.x == 0) {
+            if (dgamma) dgamma[c] = (float)sdzx;
+            if (dbeta) dbeta[c] = (float)sdz;
+        }
+    }
+    float sdy = 0.f;
+    const long nloc = (long)(b1 - b0) * TV;
+    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
+        const int bl = (int)(e / TV);
+        const int tv = (int)(e - (long)bl * TV);
+        const long off = ((long)(b0 + bl) * C + c) * T + (long)tv * VEC;
+        const Pack<VEC> d = Pack<VEC>::ld(dout + off), v = Pack<VEC>::ld(y + off);
+        Pack<VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float dz = d.v[i] * bm_act_grad(v.v[i] * sc + shf, act, leak);
+            float g = dz;
+            if (bn_train) g = sc * (dz - k1 - ((v.v[i] - mu) * is) * k2);
+            else if (scale) g = sc * dz;
+            o.v[i] = g;
+            sdy += g;
+        }
+        o.st(dy + off);
+    }
+    double acc[1] = {(double)sdy};
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc[0];
+}
+
+// out[c] = sum_split partial[c][split]
+__global__ void finalize_channel_sums_kernel(const double* __restrict__ partial, float* __restrict__ out,
+                                             int C, int nsplit) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long)c * nsplit + k];
+    out[c] = (float)s;
+}
+
+extern "C" int bm_bwd_nsplit(int B) { return B >= 64 ? 8 : (B >= 8 ? 4 : 1); }
+
+// workspace: doubles, (2*C*nsplit) for the reduce partials + (C*nsplit) for the dy sums.
+extern "C" long bm_act_bn_bwd_workspace_bytes(int B, int C) {
+    return (long)3 * C * bm_bwd_nsplit(B) * sizeof(double);
+}
+
+extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* scale,
+                             const float* shift, const float* mean, const float* invstd,
+                             int bn_train, float* dy, float* dgamma, float* dbeta, float* dbias,
+                             void* workspace, long workspace_bytes, int B, int C, int T, int act,
+                             float leak, void* stream) {
+    BM_REQUIRE(dout && y && dy, "act_bn_bwd: null pointer");
+    BM_REQUIRE(!bn_train || (scale && shift && mean && invstd), "act_bn_bwd: train BN needs saved statistics");
+    if ((long)B * C * T == 0) return BM_OK;
+    const int nsplit = bm_bwd_nsplit(B);
+    if (workspace_bytes < bm_act_bn_bwd_workspace_bytes(B, C))
+        return bm_set_error(BM_ERR_WORKSPACE, "act_bn_bwd: workspace too small (%ld < %ld)", workspace_bytes,
+                            bm_act_bn_bwd_workspace_bytes(B, C));
+    double* partial = (double*)workspace;
+    double* dy_partial = partial + (long)2 * C * nsplit;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(C, nsplit);
+    if (T % 4 == 0) {
+        if (bn_train)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
+                               invstd, partial, B, C, T, act, leak);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
+                           invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak);
+    } else {
+        if (bn_train)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
+                               invstd, partial, B, C, T, act, leak);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
+                           invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak);
+    }
+    if (dbias)
+        hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dy_partial,
+                           dbias, C, nsplit);
+    return bm_check_launch("act_bn_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel sum over (B,T): bias gradients of plain convs.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long bstride,
+                                                          double* __restrict__ partial, int B, int C,
+                                                          int T) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const int TV = T / VEC;
+    float s = 0.f;
+    const long nloc = (long)(b1 - b0) * TV;
+    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
+        const int bl = (int)(e / TV);
+        const int tv = (int)(e - (long)bl * TV);
+        const Pack<VEC> v = Pack<VEC>::ld(x + (long)(b0 + bl) * bstride + (long)c * T + (long)tv * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s += v.v[i];
+    }
+    double acc[1] = {(double)s};
+    block_sum<1>(acc, sh);
+    if (threadIdx.x == 0) partial[(long)c * nsplit + split] = acc[0];
+}
+
+extern "C" long bm_channel_sum_workspace_bytes(int B, int C) {
+    return (long)C * bm_bwd_nsplit(B) * sizeof(double);
+}
+
+extern "C" int bm_channel_sum(const float* x, long bstride, float* out, void* workspace,
+                              long workspace_bytes, int B, int C, int T, void* stream) {
+    BM_REQUIRE(x && out, "channel_sum: null pointer");
+    const int nsplit = bm_bwd_nsplit(B);
+    if (workspace_bytes < bm_channel_sum_workspace_bytes(B, C))
+        return bm_set_error(BM_ERR_WORKSPACE, "channel_sum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    if (T % 4 == 0 && bstride % 4 == 0)
+        hipLaunchKernelGGL(channel_sum_kernel<4>, dim3(C, nsplit), dim3(256), 0, s, x, bstride, partial, B, C, T);
+    else
+        hipLaunchKernelGGL(channel_sum_kernel<1>, dim3(C, nsplit), dim3(256), 0, s, x, bstride, partial, B, C, T);
+    hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, out, C,
+                       nsplit);
+    return bm_check_launch("channel_sum");
+}
+
+// ------------------------------------------------------------------------------------------------
+// GLU(dim=1): out[b][h][t] = u[b][h][t] * sigmoid(u[b][H+h][t])      (bm/models/common.py:135)
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void glu_fwd_kernel(const float* __restrict__ u, float* __restrict__ out, long nvec, int H,
+                               int T) {
+    const int TV = T / VEC;
+    const long per = (long)H * TV;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec;
+         e += (long)gridDim.x * blockDim.x) {
+        const long b = e / per;
+        const long r = e - b * per;
+        const float* ua = u + (b * 2 * H) * T + r * VEC;
+        const Pack<VEC> a = Pack<VEC>::ld(ua), g = Pack<VEC>::ld(ua + (long)H * T);
+        Pack<VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.v[i] = a.v[i] / (1.f + expf(-g.v[i]));
+        o.st(out + e * VEC);
+    }
+}
+
+extern "C" int bm_glu_fwd(const float* u, float* out, int B, int H, int T, void* stream) {
+    BM_REQUIRE(u && out, "glu_fwd: null pointer");
+    const long n = (long)B * H * T;
+    if (n == 0) return BM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (T % 4 == 0) {
+        const long nvec = n / 4;
+        const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
+        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T);
+    } else {
+        const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T);
+    }
+    return bm_check_launch("glu_fwd");
+}
+
+// du_a = dout * sig(g) ; du_g = dout * a * sig(g) * (1 - sig(g)); also per-channel sums (bias grad).
+template <int VEC>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ dout,
+                                                      const float* __restrict__ u, float* __restrict__ du,
+                                                      double* __restrict__ partial, int B, int H, int T) {
+    __shared__ double sh[4 * 2];
+    const int hch = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const int TV = T / VEC;
+    float sa = 0.f, sg = 0.f;
+    const long nloc = (long)(b1 - b0) * TV;
+    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
+        const int bl = (int)(e / TV);
+        const int tv = (int)(e - (long)bl * TV);
+        const int b = b0 + bl;
+        const long offo = ((long)b * H + hch) * T + (long)tv * VEC;
+        const long offa = ((long)b * 2 * H + hch) * T + (long)tv * VEC;
+        const long offg = offa + (long)H * T;
+        const Pack<VEC> d = Pack<VEC>::ld(dout + offo), a = Pack<VEC>::ld(u + offa), g = Pack<VEC>::ld(u + offg);
+        Pack<VEC> oa, og;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float sgm = 1.f / (1.f + expf(-g.v[i]));
+            oa.v[i] = d.v[i] * sgm;
+            og.v[i] = d.v[i] * a.v[i] * sgm * (1.f - sgm);
+            sa += oa.v[i];
+            sg += og.v[i];
+        }
+        oa.st(du + offa);
+        og.st(du + offg);
+    }
+    double acc[2] = {(double)sa, (double)sg};
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0 && partial) {
+        partial[(long)hch * nsplit + split] = acc[0];
+        partial[(long)(H + hch) * nsplit + split] = acc[1];
+    }
+}
+
+extern "C" long bm_glu_bwd_workspace_bytes(int B, int H) {
+    return (long)2 * H * bm_bwd_nsplit(B) * sizeof(double);
+}
+
+extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
+                          long workspace_bytes, int B, int H, int T, void* stream) {
+    BM_REQUIRE(dout && u && du, "glu_bwd: null pointer");
+    if ((long)B * H * T == 0) return BM_OK;
+    const int nsplit = bm_bwd_nsplit(B);
+    if (workspace_bytes < bm_glu_bwd_workspace_bytes(B, H))
+        return bm_set_error(BM_ERR_WORKSPACE, "glu_bwd: workspace too small");
+    double* partial = (double*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    if (T % 4 == 0)
+        hipLaunchKernelGGL(glu_bwd_kernel<4>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T);
+    else
+        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T);
+    if (dbias)
+        hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, s, partial,
+                           dbias, 2 * H, nsplit);
+    return bm_check_launch("glu_bwd");
+}

@@ -1,0 +1,282 @@
+"""autograd glue: each op of the SimpleConv + ClipLoss hot path as a ``torch.autograd.Function``
+whose forward AND backward are libbmhip kernels (``Solver`` calls ``loss.backward()``,
+bm/solver.py:385, so the HIP backward kernels must hang off the autograd tape).
+
+No function here touches the CPU oracle or a torch compute op for the hot path; torch is the
+tape, the allocator and the stream.
+"""
+import typing as tp
+
+import torch
+
+from . import hip_ops as H
+
+ACT_CODES = {"none": H.ACT_NONE, "gelu": H.ACT_GELU, "relu": H.ACT_RELU, "leaky": H.ACT_LEAKY}
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _conv_weight_grads(dy, x, weight_shape, KS, dil, transposed_weight):
+    """dW in the layout of the parameter: Conv1d [M,Cin,KS] or ConvTranspose1d(k=1) [Cin,M,1]."""
+    B, M, T = dy.shape
+    Cin = x.shape[1]
+    if transposed_weight:
+        out = torch.empty(weight_shape, device=dy.device, dtype=torch.float32)   # [Cin, M, 1]
+        H.gemm_nt(dy, x, B, M, Cin, T, 1, 1, out=out, out_strides=(0, 1, M, 0))
+        return out
+    return H.gemm_nt(dy, x, B, M, Cin, T, KS, dil).view(weight_shape)
+
+
+class Conv1dFn(torch.autograd.Function):
+    """nn.Conv1d ("same" padding, stride 1) or ConvTranspose1d(k=1) + bias [+ activation].
+
+    Replaces F.conv1d at bm/models/simpleconv.py:113-120 (initial_linear), :185-189 (final head)
+    and bm/models/common.py:113-114 for layers without BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil: int, act: int, leak: float, transposed_weight: bool):
+        x, weight = _c(x), _c(weight)
+        if transposed_weight:
+            Cin, M, KS = weight.shape
+            assert KS == 1, "ConvTranspose1d is only supported with kernel 1 (simpleconv.py:189)"
+            wp = H.pack_weights(weight, 1, M, Cin, 1, 0, 1, M, 0)
+        else:
+            M, Cin, KS = weight.shape
+            wp = H.pack_conv_fwd(weight)
+        need_pre = act != H.ACT_NONE and (x.requires_grad or weight.requires_grad)
+        pre, out, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, act=act, leak=leak, want_pre=need_pre)
+        ctx.save_for_backward(x, weight, pre)
+        ctx.cfg = (dil, act, leak, transposed_weight, KS, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, pre = ctx.saved_tensors
+        dil, act, leak, transposed_weight, KS, has_bias = ctx.cfg
+        dout = _c(dout)
+        dbias = None
+        if act != H.ACT_NONE:
+            dy, _, _, dbias = H.act_bn_bwd(dout, pre, None, None, None, None, False, act, leak,
+                                           want_dbias=has_bias)
+        else:
+            dy = dout
+            if has_bias:
+                dbias = H.channel_sum(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if transposed_weight:
+                Cin, M, _ = weight.shape
+                wp = H.pack_weights(weight, 1, Cin, M, 1, 0, M, 1, 0)
+            else:
+                M, Cin, _ = weight.shape
+                wp = H.pack_conv_dgrad(weight)
+            _, dx, _ = H.conv_nn(dy, wp, Cin, KS, dil)
+        dw = _conv_weight_grads(dy, x, weight.shape, KS, dil, transposed_weight) \
+            if ctx.needs_input_grad[1] else None
+        return dx, dw, dbias, None, None, None, None
+
+
+class ConvBNActFn(torch.autograd.Function):
+    """One ConvSequence layer: Conv1d -> BatchNorm1d -> activation [-> + input] as fused HIP
+    kernels (bm/models/common.py:113-119 + :146-147).
+
+    train: conv_nn (epilogue emits per-tile channel statistics) -> bn_finalize (also updates the
+    running statistics like torch) -> affine_act_res.  eval: ONE conv_nn launch with the affine,
+    activation and residual folded in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, num_batches,
+                training: bool, dil: int, act: int, leak: float, residual: bool, momentum: float,
+                eps: float):
+        x, weight = _c(x), _c(weight)
+        M, Cin, KS = weight.shape
+        B, _, T = x.shape
+        wp = H.pack_conv_fwd(weight)
+        res = x if residual else None
+        needs_grad = x.requires_grad or weight.requires_grad
+        if training:
+            pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False,
+                                      want_stats=True)
+            mean, invstd, scale, shift = H.bn_finalize(stats, B * T, gamma, beta, running_mean,
+                                                       running_var, num_batches, momentum, eps)
+            out = H.affine_act_res(pre, scale, shift, res, act, leak)
+        else:
+            mean, invstd, scale, shift = H.bn_eval_affine(gamma, beta, running_mean, running_var, eps)
+            pre, out, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, scale=scale, shift=shift, res=res,
+                                    act=act, leak=leak, want_pre=needs_grad)
+        ctx.save_for_backward(x, weight, pre, scale, shift, mean, invstd)
+        ctx.cfg = (training, dil, act, leak, residual, KS, bias is not None)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches)
+                                      if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, pre, scale, shift, mean, invstd = ctx.saved_tensors
+        training, dil, act, leak, residual, KS, has_bias = ctx.cfg
+        dout = _c(dout)
+        M, Cin, _ = weight.shape
+        dy, dgamma, dbeta, dbias = H.act_bn_bwd(dout, pre, scale, shift, mean, invstd, training, act,
+                                                leak, want_affine_grads=True, want_dbias=has_bias)
+        if not training:
+            # eval-mode BN: gamma/beta grads from the normalised input
+            dgamma = dbeta = None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight), Cin, KS, dil,
+                                 res=dout if residual else None)
+        elif residual:
+            dx = None
+        dw = H.gemm_nt(dy, x, x.shape[0], M, Cin, x.shape[2], KS, dil).view(weight.shape) \
+            if ctx.needs_input_grad[1] else None
+        return (dx, dw, dbias, dgamma, dbeta) + (None,) * 10
+
+
+class GLUConvFn(torch.autograd.Function):
+    """Conv1d(C -> 2C, k = 1 + 2*glu_context) followed by GLU(dim=1) (bm/models/common.py:133-138)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = _c(x), _c(weight)
+        M, Cin, KS = weight.shape
+        u, _, _ = H.conv_nn(x, H.pack_conv_fwd(weight), M, KS, 1, bias=bias, want_pre=True,
+                            want_out=False)
+        out = H.glu_fwd(u)
+        ctx.save_for_backward(x, weight, u)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, u = ctx.saved_tensors
+        M, Cin, KS = weight.shape
+        du, dbias = H.glu_bwd(_c(dout), u, want_dbias=ctx.has_bias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight), Cin, KS, 1)
+        dw = H.gemm_nt(du, x, x.shape[0], M, Cin, x.shape[2], KS, 1).view(weight.shape) \
+            if ctx.needs_input_grad[1] else None
+        return dx, dw, dbias
+
+
+class SubjectLayersFn(torch.autograd.Function):
+    """out[b] = W[subject[b]]^T x[b] (bm/models/common.py:55-58) as a grouped MFMA GEMM: no
+    [B, C, D] weight gather is materialised, the weight gradient is a deterministic grouped
+    reduction over the segments of each subject."""
+
+    @staticmethod
+    def forward(ctx, x, weights, subjects):
+        x, weights = _c(x), _c(weights)
+        S, C, D = weights.shape
+        widx = subjects.to(torch.int32)
+        wp = H.pack_weights(weights, S, D, C, 1, C * D, 1, D, 0)
+        _, out, _ = H.conv_nn(x, wp, D, 1, 1, widx=widx)
+        ctx.save_for_backward(x, weights, subjects, widx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weights, subjects, widx = ctx.saved_tensors
+        S, C, D = weights.shape
+        dout = _c(dout)
+        B, _, T = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpt = H.pack_weights(weights, S, C, D, 1, C * D, D, 1, 0)
+            _, dx, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=widx)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            order, seg = H.group_by_index(_c(subjects.to(torch.int64)), S)
+            dw = torch.empty_like(weights)
+            H.gemm_nt(dout, x, B, D, C, T, 1, 1, order=order, seg=seg, G=S, out=dw,
+                      out_strides=(C * D, 1, D, 0))
+        return dx, dw, None
+
+
+class ChannelMergerFn(torch.autograd.Function):
+    """Spatial attention over sensors (bm/models/common.py:334-358), computed once per distinct
+    sensor layout in the batch: positions_u [U, C, 2], layout_index [B] -> which layout a segment
+    uses.  ``ban`` = (centre tensor [2], radius) for the training-time sensor dropout (:342-346)."""
+
+    @staticmethod
+    def forward(ctx, meg, heads, positions_u, layout_index, ban_center, ban_radius: float):
+        meg, heads, positions_u = _c(meg), _c(heads), _c(positions_u)
+        U, C, _ = positions_u.shape
+        O, D = heads.shape
+        emb = H.fourier_emb(positions_u, D)
+        seg = torch.arange(U + 1, dtype=torch.int32, device=meg.device)
+        scores = H.gemm_nt(heads, emb, U, O, C, D, a_strides=(0, D), x_strides=(C * D, D), seg=seg,
+                           G=U).view(U, O, C)
+        weights = H.masked_softmax(scores, positions_u, ban_center, ban_radius)
+        widx = layout_index.to(torch.int32)
+        wp = H.pack_weights(weights, U, O, C, 1, O * C, C, 1, 0)
+        _, out, _ = H.conv_nn(meg, wp, O, 1, 1, widx=widx)
+        ctx.save_for_backward(meg, emb, weights, layout_index)
+        ctx.dims = (U, C, O, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        meg, emb, weights, layout_index = ctx.saved_tensors
+        U, C, O, D = ctx.dims
+        dout = _c(dout)
+        B, _, T = meg.shape
+        dheads = None
+        if ctx.needs_input_grad[1]:
+            order, seg = H.group_by_index(_c(layout_index.to(torch.int64)), U)
+            dweights = H.gemm_nt(dout, meg, B, O, C, T, 1, 1, order=order, seg=seg, G=U).view(U, O, C)
+            dscores = H.softmax_bwd(weights, dweights)
+            wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0)
+            uidx = torch.arange(U, dtype=torch.int32, device=meg.device)
+            _, per_layout, _ = H.conv_nn(emb, wp, O, 1, 1, widx=uidx)        # [U, O, D]
+            dheads = H.sum_over_batch(per_layout) if U > 1 else per_layout[0]
+        dmeg = None
+        if ctx.needs_input_grad[0]:
+            wpt = H.pack_weights(weights, U, C, O, 1, O * C, 1, C, 0)
+            _, dmeg, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=layout_index.to(torch.int32))
+        return dmeg, dheads, None, None, None, None
+
+
+class ClipLossFn(torch.autograd.Function):
+    """ClipLoss.forward (bm/losses.py:104-114): scores = est . cand^T * inv_norm (split-K MFMA GEMM
+    over K = F*T), row-wise cross entropy with the target on the diagonal; the backward is a second
+    MFMA GEMM dEst = dScores . cand."""
+
+    @staticmethod
+    def forward(ctx, estimate, candidate):
+        estimate, candidate = _c(estimate), _c(candidate)
+        B, Bc = estimate.shape[0], candidate.shape[0]
+        K = estimate.numel() // B
+        assert candidate.numel() // Bc == K
+        inv = H.clip_inv_norms(candidate)
+        part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+        scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True)
+        ctx.save_for_backward(candidate, dscaled)
+        ctx.shape = estimate.shape
+        ctx.mark_non_differentiable(scores)
+        return loss, scores
+
+    @staticmethod
+    def backward(ctx, dloss, _dscores):
+        candidate, dscaled = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("ClipLoss: gradients w.r.t. candidates (learnable feature "
+                                      "model) are not implemented on the HIP path yet")
+        B, Bc = dscaled.shape
+        K = candidate.numel() // Bc
+        wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=_c(dloss).view(1))
+        _, dest, _ = H.conv_nn(candidate.view(1, Bc, K), wp, B, 1, 1)
+        return dest.view(ctx.shape), None
+
+
+def clip_scores(estimate, candidate, want_probs=False):
+    """ClipLoss.get_scores / get_probabilities (bm/losses.py:77-102), no autograd."""
+    estimate, candidate = _c(estimate), _c(candidate)
+    B, Bc = estimate.shape[0], candidate.shape[0]
+    K = estimate.numel() // B
+    inv = H.clip_inv_norms(candidate)
+    part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+    scores, probs, _, _ = H.clip_ce(part, inv, want_probs=want_probs)
+    return probs if want_probs else scores

@@ -1,0 +1,311 @@
+"""Typed Python wrappers over the libbmhip C-ABI (one wrapper per entry point group).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream: every function
+checks that its tensors are fp32 / contiguous / on the GPU, allocates outputs with ``torch.empty``
+and enqueues the HIP kernels on the current stream.  CPU tensors are rejected -- there is no
+fallback path.
+"""
+import ctypes
+import typing as tp
+
+import torch
+
+from ._lib import lib, check, BmHipError
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
+BKC = 16
+
+
+def _p(t: tp.Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise BmHipError(f"{name}: expected a GPU tensor; the brainmagick_amd hot path has no CPU "
+                         "fallback (got %s)" % (t.device if isinstance(t, torch.Tensor) else type(t)))
+    if t.dtype != dtype:
+        raise BmHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise BmHipError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _opt(t, name, dtype=torch.float32):
+    return None if t is None else _req(t, name, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+def conv_mpad(M: int) -> int:
+    return lib().bm_conv_mpad(M)
+
+
+def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, sm: int, sc: int,
+                 sj: int, flip: bool = False, alpha: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(src, "pack_weights.src")
+    n = lib().bm_packed_weight_elems(G, M, Cin, KS)
+    dst = torch.empty(n, device=src.device, dtype=torch.float32)
+    check(lib().bm_pack_weights(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
+                                _p(_opt(alpha, "alpha")), _stream()), "bm_pack_weights")
+    return dst
+
+
+def pack_conv_fwd(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Conv1d weight [M, Cin, KS] for the forward conv."""
+    M, Cin, KS = weight.shape
+    return pack_weights(weight, 1, M, Cin, KS, 0, Cin * KS, KS, 1)
+
+
+def pack_conv_dgrad(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Conv1d weight [M, Cin, KS] for the data gradient: roles of M/Cin swapped, taps flipped."""
+    M, Cin, KS = weight.shape
+    return pack_weights(weight, 1, Cin, M, KS, 0, KS, Cin * KS, 1, flip=True)
+
+
+def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: int = 1,
+            widx: tp.Optional[torch.Tensor] = None, bias=None, scale=None, shift=None, res=None,
+            act: int = ACT_NONE, leak: float = 0., want_pre: bool = False, want_out: bool = True,
+            want_stats: bool = False):
+    """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T]."""
+    _req(x, "conv_nn.x")
+    _req(wpacked, "conv_nn.w")
+    B, Cin, T = x.shape
+    y_pre = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_pre else None
+    y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
+    stats = None
+    if want_stats:
+        stats = torch.empty(lib().bm_conv_stats_tiles(B, T), M, 2, device=x.device,
+                            dtype=torch.float32)
+    if res is not None:
+        _req(res, "conv_nn.res")
+        assert res.shape == (B, M, T), (res.shape, (B, M, T))
+    check(lib().bm_conv1d_nn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
+                             _p(_opt(bias, "bias")), _p(_opt(scale, "scale")),
+                             _p(_opt(shift, "shift")), _p(res), M * T, _p(y_pre), _p(y_out), M * T,
+                             _p(stats), B, Cin, M, T, KS, dil, act, leak, _stream()),
+          "bm_conv1d_nn")
+    return y_pre, y_out, stats
+
+
+def group_by_index(idx: torch.Tensor, G: int):
+    """idx [B] int64 -> (order [B] int32, seg [G+1] int32)."""
+    _req(idx, "group_by_index.idx", torch.int64)
+    B = idx.numel()
+    order = torch.empty(B, device=idx.device, dtype=torch.int32)
+    seg = torch.empty(G + 1, device=idx.device, dtype=torch.int32)
+    check(lib().bm_group_by_index(_p(idx), B, G, _p(order), _p(seg), None, _stream()),
+          "bm_group_by_index")
+    return order, seg
+
+
+def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, KS: int = 1,
+            dil: int = 1, a_strides=None, x_strides=None, order=None, seg=None, G: int = 1,
+            out: tp.Optional[torch.Tensor] = None, out_strides=None, nsplit: tp.Optional[int] = None):
+    """out[g*sg + m*sm + c*sc + j*sj] = sum_{s in g} sum_t a[s][m][t] * x[s][c][t + shift_j].
+
+    a_strides / x_strides = (segment stride, row stride) in elements; defaults are contiguous
+    [S][rows][T].  Default ``out`` is [G][M][Cn][KS] contiguous."""
+    _req(a, "gemm_nt.a")
+    _req(x, "gemm_nt.x")
+    if a_strides is None:
+        a_strides = (M * T, T)
+    if x_strides is None:
+        x_strides = (Cn * T, T)
+    if out_strides is None:
+        out_strides = (M * Cn * KS, Cn * KS, KS, 1)
+    if out is None:
+        out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
+    if nsplit is None:
+        nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G)
+        if G > 1:
+            tiles = max(1, (M // 64) * (Cn // 64)) * G
+            nsplit = max(1, min(8, 512 // tiles)) if T >= 1024 else 1
+    canonical = tuple(out_strides) == (M * Cn * KS, Cn * KS, KS, 1)
+    if nsplit == 1 and canonical:
+        part = out
+    else:
+        part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
+    check(lib().bm_gemm_nt(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
+                           _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)),
+                           _p(part), S, G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
+    if part is not out:
+        check(lib().bm_reduce_splits(_p(part), _p(out), G, nsplit, M, Cn, KS, *out_strides,
+                                     _stream()), "bm_reduce_splits")
+    return out
+
+
+def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
+    """Split-K partial tiles [nsplit][M][Cn] (KS=1, one group), consumed by clip_ce."""
+    _req(a, "gemm_nt.a")
+    _req(x, "gemm_nt.x")
+    if nsplit is None:
+        nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, 1, S, T, 1)
+    part = torch.empty(nsplit, M, Cn, device=a.device, dtype=torch.float32)
+    check(lib().bm_gemm_nt(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
+                           None, None, _p(part), S, 1, M, Cn, T, 1, 1, nsplit, _stream()),
+          "bm_gemm_nt")
+    return part
+
+
+def sum_over_batch(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "sum_over_batch.x")
+    B = x.shape[0]
+    out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
+    check(lib().bm_sum_over_batch(_p(x), _p(out), B, out.numel(), _stream()), "bm_sum_over_batch")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def bn_finalize(stats, count: int, gamma, beta, running_mean, running_var, num_batches,
+                momentum: float, eps: float):
+    _req(stats, "bn_finalize.stats")
+    ntiles, C, _ = stats.shape
+    mean, invstd, scale, shift = (torch.empty(C, device=stats.device, dtype=torch.float32)
+                                  for _ in range(4))
+    check(lib().bm_bn_finalize(_p(stats), ntiles, C, count, _p(_opt(gamma, "gamma")),
+                               _p(_opt(beta, "beta")), _p(_opt(running_mean, "running_mean")),
+                               _p(_opt(running_var, "running_var")),
+                               _p(_opt(num_batches, "num_batches", torch.int64)), momentum, eps,
+                               _p(mean), _p(invstd), _p(scale), _p(shift), _stream()),
+          "bm_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
+    _req(running_mean, "running_mean")
+    C = running_mean.numel()
+    mean, invstd, scale, shift = (torch.empty(C, device=running_mean.device, dtype=torch.float32)
+                                  for _ in range(4))
+    check(lib().bm_bn_eval_affine(C, _p(_opt(gamma, "gamma")), _p(_opt(beta, "beta")),
+                                  _p(running_mean), _p(_req(running_var, "running_var")), eps,
+                                  _p(mean), _p(invstd), _p(scale), _p(shift), _stream()),
+          "bm_bn_eval_affine")
+    return mean, invstd, scale, shift
+
+
+def affine_act_res(y, scale, shift, res, act: int, leak: float = 0.):
+    _req(y, "affine_act_res.y")
+    B, C, T = y.shape
+    out = torch.empty_like(y)
+    check(lib().bm_affine_act_res(_p(y), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")),
+                                  _p(_opt(res, "res")), _p(out), B, C, T, act, leak, _stream()),
+          "bm_affine_act_res")
+    return out
+
+
+def act_bn_bwd(dout, y, scale, shift, mean, invstd, bn_train: bool, act: int, leak: float = 0.,
+               want_affine_grads: bool = False, want_dbias: bool = True):
+    """Returns (dy, dgamma | None, dbeta | None, dbias | None)."""
+    _req(dout, "act_bn_bwd.dout")
+    _req(y, "act_bn_bwd.y")
+    B, C, T = y.shape
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine_grads else None
+    dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine_grads else None
+    dbias = torch.empty(C, device=y.device, dtype=torch.float32) if want_dbias else None
+    nbytes = lib().bm_act_bn_bwd_workspace_bytes(B, C)
+    ws = torch.empty(nbytes, device=y.device, dtype=torch.uint8)
+    check(lib().bm_act_bn_bwd(_p(dout), _p(y), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")),
+                              _p(_opt(mean, "mean")), _p(_opt(invstd, "invstd")), int(bn_train),
+                              _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), nbytes, B, C, T, act,
+                              leak, _stream()), "bm_act_bn_bwd")
+    return dy, dgamma, dbeta, dbias
+
+
+def channel_sum(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "channel_sum.x")
+    B, C, T = x.shape
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    nbytes = lib().bm_channel_sum_workspace_bytes(B, C)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(lib().bm_channel_sum(_p(x), C * T, _p(out), _p(ws), nbytes, B, C, T, _stream()),
+          "bm_channel_sum")
+    return out
+
+
+def glu_fwd(u: torch.Tensor) -> torch.Tensor:
+    _req(u, "glu_fwd.u")
+    B, C2, T = u.shape
+    out = torch.empty(B, C2 // 2, T, device=u.device, dtype=torch.float32)
+    check(lib().bm_glu_fwd(_p(u), _p(out), B, C2 // 2, T, _stream()), "bm_glu_fwd")
+    return out
+
+
+def glu_bwd(dout: torch.Tensor, u: torch.Tensor, want_dbias: bool = True):
+    _req(dout, "glu_bwd.dout")
+    _req(u, "glu_bwd.u")
+    B, C2, T = u.shape
+    H = C2 // 2
+    du = torch.empty_like(u)
+    dbias = torch.empty(C2, device=u.device, dtype=torch.float32) if want_dbias else None
+    nbytes = lib().bm_glu_bwd_workspace_bytes(B, H)
+    ws = torch.empty(nbytes, device=u.device, dtype=torch.uint8)
+    check(lib().bm_glu_bwd(_p(dout), _p(u), _p(du), _p(dbias), _p(ws), nbytes, B, H, T, _stream()),
+          "bm_glu_bwd")
+    return du, dbias
+
+
+# ------------------------------------------------------------------------------------------------
+def fourier_emb(positions: torch.Tensor, D: int, margin: float = 0.2) -> torch.Tensor:
+    _req(positions, "fourier_emb.positions")
+    rows = positions.numel() // 2
+    emb = torch.empty(*positions.shape[:-1], D, device=positions.device, dtype=torch.float32)
+    check(lib().bm_fourier_emb(_p(positions), _p(emb), rows, D, margin, _stream()), "bm_fourier_emb")
+    return emb
+
+
+def masked_softmax(scores, positions, ban_center, ban_radius: float) -> torch.Tensor:
+    _req(scores, "masked_softmax.scores")
+    _req(positions, "masked_softmax.positions")
+    U, O, C = scores.shape
+    w = torch.empty_like(scores)
+    check(lib().bm_masked_softmax(_p(scores), _p(positions), _p(_opt(ban_center, "ban_center")),
+                                  float(ban_radius), _p(w), U, O, C, _stream()), "bm_masked_softmax")
+    return w
+
+
+def softmax_bwd(w, dw) -> torch.Tensor:
+    _req(w, "softmax_bwd.w")
+    _req(dw, "softmax_bwd.dw")
+    ds = torch.empty_like(w)
+    C = w.shape[-1]
+    check(lib().bm_softmax_bwd(_p(w), _p(dw), _p(ds), w.numel() // C, C, _stream()),
+          "bm_softmax_bwd")
+    return ds
+
+
+# ------------------------------------------------------------------------------------------------
+def clip_inv_norms(cand: torch.Tensor) -> torch.Tensor:
+    _req(cand, "clip_inv_norms.cand")
+    Bc = cand.shape[0]
+    K = cand.numel() // max(Bc, 1)
+    out = torch.empty(Bc, device=cand.device, dtype=torch.float32)
+    check(lib().bm_clip_inv_norms(_p(cand), Bc, K, _p(out), _stream()), "bm_clip_inv_norms")
+    return out
+
+
+def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False):
+    """part [nsplit][B][B'] -> (scores, probs|None, dscaled|None, loss|None)."""
+    _req(part, "clip_ce.part")
+    nsplit, B, Bc = part.shape
+    dev = part.device
+    scores = torch.empty(B, Bc, device=dev, dtype=torch.float32)
+    probs = torch.empty(B, Bc, device=dev, dtype=torch.float32) if want_probs else None
+    dscaled = torch.empty(B, Bc, device=dev, dtype=torch.float32) if want_grad else None
+    loss_row = torch.empty(B, device=dev, dtype=torch.float32) if want_loss else None
+    loss = torch.empty((), device=dev, dtype=torch.float32) if want_loss else None
+    check(lib().bm_clip_ce(_p(part), nsplit, _p(_req(inv_norm, "inv_norm")), _p(scores), _p(probs),
+                           _p(dscaled), _p(loss_row), _p(loss), B, Bc, _stream()), "bm_clip_ce")
+    return scores, probs, dscaled, loss
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float, beta2: float,
+              eps: float, grad_scale: float = 1.0):
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t, f"adam_step.{n}")
+    check(lib().bm_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), step,
+                             lr, beta1, beta2, eps, grad_scale, _stream()), "bm_adam_step")

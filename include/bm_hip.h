@@ -1,0 +1,112 @@
+/* libbmhip -- C-ABI of the MI355X (gfx950) SimpleConv + ClipLoss training hot path.
+ *
+ * The reference (facebookresearch/brainmagick) is 100 % Python: its "FFI" for this path is the set
+ * of PyTorch ops its modules call.  Each entry point below replaces the ATen kernels behind one such
+ * call site (cited as bm/<file>:<line>, relative to the reference root).  The reference-side binding
+ * is the ctypes table in brainmagick_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, otherwise a hipError_t or a BM_ERR_* code; the message is
+ *     available (thread-local) from bm_last_error().  Nothing aborts or throws across the ABI.
+ *   - all tensors are fp32, contiguous, [B][channels][T] with T fastest, living in device memory
+ *     owned by the caller.  Indices are int32 (widx, order, seg) or int64 (idx of group_by_index).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); kernels are
+ *     only enqueued, never synchronised.  The library allocates nothing; scratch is caller-provided.
+ *   - deterministic: every reduction has a fixed order (split-K partials are folded in order).
+ */
+#ifndef BM_HIP_H
+#define BM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BM_ACT_NONE 0
+#define BM_ACT_GELU 1   /* exact erf GELU, nn.GELU()          bm/models/simpleconv.py:85-86 */
+#define BM_ACT_RELU 2   /* nn.ReLU                             bm/models/simpleconv.py:89-90 */
+#define BM_ACT_LEAKY 3  /* nn.LeakyReLU(relu_leakiness)        bm/models/simpleconv.py:87-88 */
+
+/* ---- core ---- */
+int bm_version(void);
+const char* bm_last_error(void);
+int bm_device_count(void);
+
+/* ---- weight packing / grouping / split-K folding (pack.hip) ---- */
+/* Tile geometry helpers shared with the host side. */
+int bm_conv_mt_for(int M);
+int bm_conv_mpad(int M);
+int bm_conv_stats_tiles(int B, int T);
+long bm_packed_weight_elems(int G, int M, int Cin, int KS);
+/* dst[g][chunk][tap][16][Mpad] <- alpha * src[g*sg + m*sm + c*sc + tap'*sj]  (tap' flipped if flip).
+ * Expresses nn.Conv1d weights (fwd and data-grad), SubjectLayers.weights (bm/models/common.py:49),
+ * ConvTranspose1d(k=1) weights (simpleconv.py:189) and attention weights (common.py:357). */
+int bm_pack_weights(const float* src, float* dst, int G, int M, int Cin, int KS, long sg, long sm,
+                    long sc, long sj, int flip, const float* alpha_ptr, void* stream);
+/* Stable grouping of segments by subject / layout index; replaces the gather at common.py:57. */
+int bm_group_by_index(const long* idx, int B, int G, int* order, int* seg, int* err_flag, void* stream);
+int bm_reduce_splits(const float* part, float* out, int G, int nsplit, int M, int Cn, int KS, long sg,
+                     long sm, long sc, long sj, void* stream);
+int bm_sum_over_batch(const float* x, float* out, int B, long n, void* stream);
+
+/* ---- implicit-GEMM conv, fp32 MFMA (conv_nn.hip) ----
+ * y[b][m][t] = ep(bias[m] + sum_{c,j} W[widx[b]][m][c][j] * x[b][c][t + (j-KS/2)*dil]).
+ * Replaces F.conv1d (bm/models/common.py:113-114,133-138; simpleconv.py:113-120,185-189), the
+ * einsums of SubjectLayers (common.py:58) and ChannelMerger (common.py:358), their data-gradients
+ * and ClipLoss' dEstimate (losses.py:94 backward).  y_pre = value after bias; y_out = after
+ * [affine ->] act [-> + res]; stats = per-tile (sum, sumsq) of y_pre for BatchNorm1d (common.py:119). */
+int bm_conv1d_nn(const float* x, long x_bstride, const float* wpacked, const int* widx,
+                 const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                 long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
+                 int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
+
+/* ---- time-contraction GEMM, fp32 MFMA, split-K (gemm_nt.hip) ----
+ * part[g,split][m][c*KS+j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j-KS/2)*dil].
+ * Replaces aten::convolution_backward (weight part), the weight-grad einsums of SubjectLayers /
+ * ChannelMerger, torch.einsum("bct,oct,o->bo") (losses.py:94) and einsum("bcd,bod->boc") (common.py:355). */
+int bm_gemm_nt_suggest_splits(int M, int Cn, int KS, int S, int T, int G);
+int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
+               long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
+               int Cn, int T, int KS, int dil, int nsplit, void* stream);
+
+/* ---- BatchNorm1d / activation / residual / GLU (norm_act.hip)  bm/models/common.py:113-151 ---- */
+int bm_bn_finalize(const float* stats, int ntiles, int C, long count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, long* num_batches,
+                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                   void* stream);
+int bm_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                      float* shift, void* stream);
+int bm_affine_act_res(const float* y, const float* scale, const float* shift, const float* res,
+                      float* out, int B, int C, int T, int act, float leak, void* stream);
+int bm_bwd_nsplit(int B);
+long bm_act_bn_bwd_workspace_bytes(int B, int C);
+int bm_act_bn_bwd(const float* dout, const float* y, const float* scale, const float* shift,
+                  const float* mean, const float* invstd, int bn_train, float* dy, float* dgamma,
+                  float* dbeta, float* dbias, void* workspace, long workspace_bytes, int B, int C,
+                  int T, int act, float leak, void* stream);
+long bm_channel_sum_workspace_bytes(int B, int C);
+int bm_channel_sum(const float* x, long bstride, float* out, void* workspace, long workspace_bytes,
+                   int B, int C, int T, void* stream);
+int bm_glu_fwd(const float* u, float* out, int B, int H, int T, void* stream);
+long bm_glu_bwd_workspace_bytes(int B, int H);
+int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
+               long workspace_bytes, int B, int H, int T, void* stream);
+
+/* ---- ChannelMerger front end (merger.hip)  bm/models/common.py:239-271,334-357 ---- */
+int bm_fourier_emb(const float* positions, float* emb, long rows, int D, float margin, void* stream);
+int bm_masked_softmax(const float* scores, const float* positions, const float* ban_center,
+                      float ban_radius, float* weights, int U, int O, int C, void* stream);
+int bm_softmax_bwd(const float* w, const float* dw, float* ds, long rows, int C, void* stream);
+
+/* ---- ClipLoss (clip.hip)  bm/losses.py:77-114 ---- */
+int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_norm, void* stream);
+int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores, float* probs,
+               float* dscaled, float* loss_row, float* loss, int B, int Bc, void* stream);
+
+/* ---- fused Adam on the flat bucket (adam.hip)  torch.optim.Adam @ bm/train.py:118-119 ---- */
+int bm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
+                 double lr, double beta1, double beta2, double eps, double grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BM_HIP_H */

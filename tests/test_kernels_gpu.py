@@ -1,0 +1,286 @@
+"""Per-kernel parity: each libbmhip entry point (called through the C-ABI) vs the CPU oracle /
+an fp64 torch CPU restatement of the same op, on seeded inputs.  fp32 tolerances are written in
+each test (rel-L2 unless stated)."""
+import math
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+from helpers import rel_l2
+from oracle import bm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 5e-6     # fp32 MFMA (exact fp32 FMA chain) vs fp64 reference
+GRAD_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    from brainmagick_amd import hip_ops
+    return hip_ops
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+CONV_CASES = [
+    # Cin, M, KS, dil, T, B
+    (270, 320, 3, 1, 360, 3),
+    (320, 320, 3, 16, 343, 2),
+    (320, 640, 3, 1, 361, 2),
+    (320, 640, 1, 1, 360, 2),
+    (640, 120, 1, 1, 97, 3),
+    (20, 12, 1, 1, 48, 5),
+    (33, 40, 5, 8, 100, 2),
+    (16, 16, 3, 4, 7, 1),      # T smaller than the dilation halo
+    (5, 1024, 1, 1, 130, 1),
+]
+
+
+@pytest.mark.parametrize("Cin,M,KS,dil,T,B", CONV_CASES)
+def test_conv_nn_forward(H, Cin, M, KS, dil, T, B):
+    g = _gen(Cin * 7 + M + KS + dil + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
+    b = torch.randn(M, generator=g)
+    ref = F.conv1d(x.double(), w.double(), b.double(), padding=KS // 2 * dil, dilation=dil)
+    wp = H.pack_conv_fwd(w.cuda())
+    _, y, _ = H.conv_nn(x.cuda(), wp, M, KS, dil, bias=b.cuda())
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < FWD_TOL
+
+
+def test_conv_nn_epilogue_and_stats(H):
+    g = _gen(5)
+    B, Cin, M, T, KS, dil = 3, 48, 70, 200, 3, 2
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
+    b = torch.randn(M, generator=g)
+    scale = torch.rand(M, generator=g) + 0.5
+    shift = torch.randn(M, generator=g)
+    res = torch.randn(B, M, T, generator=g)
+    pre_ref = F.conv1d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    for act, fn in [(H.ACT_GELU, F.gelu), (H.ACT_RELU, F.relu),
+                    (H.ACT_LEAKY, lambda z: F.leaky_relu(z, 0.1)), (H.ACT_NONE, lambda z: z)]:
+        out_ref = fn(pre_ref * scale.double()[None, :, None] + shift.double()[None, :, None]) \
+            + res.double()
+        pre, out, stats = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda()), M, KS, dil, bias=b.cuda(),
+                                    scale=scale.cuda(), shift=shift.cuda(), res=res.cuda(), act=act,
+                                    leak=0.1, want_pre=True, want_stats=True)
+        assert rel_l2(pre, pre_ref) < FWD_TOL
+        assert rel_l2(out, out_ref) < FWD_TOL
+        s = stats.double().cpu().sum(0)
+        assert rel_l2(s[:, 0], pre_ref.sum((0, 2))) < 1e-5
+        assert rel_l2(s[:, 1], (pre_ref ** 2).sum((0, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("Cin,M,KS,dil,T,B", CONV_CASES[:7])
+def test_conv_backward_kernels(H, Cin, M, KS, dil, T, B):
+    g = _gen(Cin + M * 3 + KS + dil + T)
+    x = torch.randn(B, Cin, T, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(M, Cin, KS, generator=g, dtype=torch.float64) / math.sqrt(Cin * KS)) \
+        .requires_grad_(True)
+    dy = torch.randn(B, M, T, generator=g, dtype=torch.float64)
+    y = F.conv1d(x, w, None, padding=KS // 2 * dil, dilation=dil)
+    y.backward(dy)
+    dyg, xg, wg = dy.float().cuda(), x.detach().float().cuda(), w.detach().float().cuda()
+    _, dx, _ = H.conv_nn(dyg, H.pack_conv_dgrad(wg), Cin, KS, dil)
+    assert rel_l2(dx, x.grad) < GRAD_TOL
+    dw = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil)
+    assert dw.shape == (1, M, Cin, KS)
+    assert rel_l2(dw[0], w.grad) < GRAD_TOL
+    for nsplit in (1, 3):
+        dw2 = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil, nsplit=nsplit)
+        assert rel_l2(dw2[0], w.grad) < GRAD_TOL
+
+
+def test_conv_deterministic(H):
+    g = _gen(11)
+    x = torch.randn(4, 64, 360, generator=g).cuda()
+    dy = torch.randn(4, 96, 360, generator=g).cuda()
+    a = H.gemm_nt(dy, x, 4, 96, 64, 360, 3, 2)
+    b = H.gemm_nt(dy, x, 4, 96, 64, 360, 3, 2)
+    assert torch.equal(a, b)
+
+
+def test_subject_layers_kernels(H):
+    """bm/models/common.py:55-58 forward and both gradients, grouped by subject."""
+    g = _gen(3)
+    B, C, D, T, S = 9, 37, 45, 120, 4
+    x = torch.randn(B, C, T, generator=g, dtype=torch.float64, requires_grad=True)
+    W = torch.randn(S, C, D, generator=g, dtype=torch.float64, requires_grad=True)
+    subj = torch.tensor([2, 0, 2, 3, 3, 3, 0, 2, 2])        # subject 1 is absent from the batch
+    ref = O.subject_layers(x, W, subj)
+    dy = torch.randn(B, D, T, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    xg, Wg, dyg = x.detach().float().cuda(), W.detach().float().cuda(), dy.float().cuda()
+    widx = subj.to(torch.int32).cuda()
+    wp = H.pack_weights(Wg, S, D, C, 1, C * D, 1, D, 0)
+    _, y, _ = H.conv_nn(xg, wp, D, 1, 1, widx=widx)
+    assert rel_l2(y, ref) < FWD_TOL
+    wpt = H.pack_weights(Wg, S, C, D, 1, C * D, D, 1, 0)
+    _, dx, _ = H.conv_nn(dyg, wpt, C, 1, 1, widx=widx)
+    assert rel_l2(dx, x.grad) < GRAD_TOL
+    order, seg = H.group_by_index(subj.cuda(), S)
+    assert seg.tolist() == [0, 2, 2, 6, 9]
+    assert order.tolist() == [1, 6, 0, 2, 7, 8, 3, 4, 5]
+    dW = torch.empty(S, C, D, device="cuda")
+    H.gemm_nt(dyg, xg, B, D, C, T, 1, 1, order=order, seg=seg, G=S, out=dW,
+              out_strides=(C * D, 1, D, 0))
+    assert rel_l2(dW, W.grad) < GRAD_TOL
+    assert torch.count_nonzero(dW[1]) == 0
+
+
+@pytest.mark.parametrize("T", [360, 343])
+@pytest.mark.parametrize("act", ["gelu", "relu", "leaky"])
+def test_batchnorm_act_residual(H, T, act):
+    """conv -> BatchNorm1d(train) -> act -> + residual, forward and backward (common.py:113-151)."""
+    g = _gen(T)
+    B, C = 6, 40
+    code = {"gelu": H.ACT_GELU, "relu": H.ACT_RELU, "leaky": H.ACT_LEAKY}[act]
+    fn = {"gelu": F.gelu, "relu": F.relu, "leaky": lambda z: F.leaky_relu(z, 0.1)}[act]
+    y = (torch.randn(B, C, T, generator=g, dtype=torch.float64) * 2 + 0.7).requires_grad_(True)
+    res = torch.randn(B, C, T, generator=g, dtype=torch.float64)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    rm = torch.randn(C, generator=g, dtype=torch.float64)
+    rv = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    out_ref = fn(F.batch_norm(y, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1,
+                              eps=1e-5)) + res
+    dout = torch.randn(B, C, T, generator=g, dtype=torch.float64)
+    out_ref.backward(dout)
+
+    # per-tile (sum, sumsq) partials as conv_nn's epilogue would produce them
+    yf = y.detach().float()
+    ntn = (T + 127) // 128
+    stats = torch.zeros(B * ntn, C, 2)
+    for b in range(B):
+        for n in range(ntn):
+            sl = yf[b, :, n * 128:(n + 1) * 128]
+            stats[b * ntn + n, :, 0] = sl.sum(1)
+            stats[b * ntn + n, :, 1] = (sl * sl).sum(1)
+    rm_g, rv_g = rm.float().cuda(), rv.float().cuda()
+    nb = torch.zeros((), dtype=torch.int64, device="cuda")
+    mean, invstd, scale, shift = H.bn_finalize(stats.cuda(), B * T, gamma.detach().float().cuda(),
+                                               beta.detach().float().cuda(), rm_g, rv_g, nb, 0.1, 1e-5)
+    assert int(nb) == 1
+    assert rel_l2(rm_g, rm_ref) < 1e-6 and rel_l2(rv_g, rv_ref) < 1e-6
+    out = H.affine_act_res(yf.cuda(), scale, shift, res.float().cuda(), code, 0.1)
+    assert rel_l2(out, out_ref) < FWD_TOL
+    dy, dgamma, dbeta, dbias = H.act_bn_bwd(dout.float().cuda(), yf.cuda(), scale, shift, mean, invstd,
+                                            True, code, 0.1, want_affine_grads=True)
+    assert rel_l2(dy, y.grad) < GRAD_TOL
+    assert rel_l2(dgamma, gamma.grad) < GRAD_TOL
+    assert rel_l2(dbeta, beta.grad) < GRAD_TOL
+    assert dbias.abs().max().item() < 1e-3          # sum(dy) of a BN input is ~0
+
+    # eval mode: running statistics
+    y2 = y.detach().clone().requires_grad_(True)
+    out_ref = fn(F.batch_norm(y2, rm, rv, gamma.detach(), beta.detach(), training=False, eps=1e-5))
+    out_ref.backward(dout)
+    mean, invstd, scale, shift = H.bn_eval_affine(gamma.detach().float().cuda(),
+                                                  beta.detach().float().cuda(), rm.float().cuda(),
+                                                  rv.float().cuda(), 1e-5)
+    out = H.affine_act_res(yf.cuda(), scale, shift, None, code, 0.1)
+    assert rel_l2(out, out_ref) < FWD_TOL
+    dy, _, _, dbias = H.act_bn_bwd(dout.float().cuda(), yf.cuda(), scale, shift, mean, invstd, False,
+                                   code, 0.1)
+    assert rel_l2(dy, y2.grad) < GRAD_TOL
+    assert rel_l2(dbias, y2.grad.sum((0, 2))) < GRAD_TOL
+    # no BN at all
+    y3 = y.detach().clone().requires_grad_(True)
+    fn(y3).backward(dout)
+    dy, _, _, _ = H.act_bn_bwd(dout.float().cuda(), yf.cuda(), None, None, None, None, False, code, 0.1)
+    assert rel_l2(dy, y3.grad) < GRAD_TOL
+
+
+@pytest.mark.parametrize("T", [360, 79])
+def test_glu_and_channel_sum(H, T):
+    g = _gen(T + 1)
+    B, Hc = 5, 24
+    u = torch.randn(B, 2 * Hc, T, generator=g, dtype=torch.float64, requires_grad=True)
+    ref = F.glu(u, dim=1)
+    dout = torch.randn(B, Hc, T, generator=g, dtype=torch.float64)
+    ref.backward(dout)
+    out = H.glu_fwd(u.detach().float().cuda())
+    assert rel_l2(out, ref) < FWD_TOL
+    du, dbias = H.glu_bwd(dout.float().cuda(), u.detach().float().cuda())
+    assert rel_l2(du, u.grad) < GRAD_TOL
+    assert rel_l2(dbias, u.grad.sum((0, 2))) < GRAD_TOL
+    assert rel_l2(H.channel_sum(du), u.grad.sum((0, 2))) < GRAD_TOL
+
+
+def test_merger_kernels(H):
+    """FourierEmb + masked softmax over sensors + weighted reduction (common.py:239-271,334-358)."""
+    g = _gen(8)
+    U, C, Oc, D, T = 3, 45, 30, 128, 90
+    pos = torch.rand(U, C, 2, generator=g)
+    pos[1, 30:] = O.INVALID
+    heads = torch.randn(Oc, D, generator=g) / D ** 0.5
+    emb_ref = O.fourier_emb(pos, D)
+    emb = H.fourier_emb(pos.cuda(), D)
+    assert (emb.cpu() - emb_ref).abs().max().item() < 5e-6
+    ban = torch.tensor([0.4, 0.6])
+    for training, radius in [(False, 0.0), (True, 0.2)]:
+        w_ref = O.merger_weights(heads.double(), pos.double(), training, 0.2, ban.double())
+        scores = H.gemm_nt(heads.cuda(), emb, U, Oc, C, D, a_strides=(0, D), x_strides=(C * D, D),
+                           seg=torch.arange(U + 1, dtype=torch.int32).cuda(), G=U)[..., 0]
+        w = H.masked_softmax(scores.contiguous(), pos.cuda(), ban.cuda() if radius else None, radius)
+        assert rel_l2(w, w_ref) < 2e-5
+        assert torch.count_nonzero(w[1, :, 30:]) == 0
+    # backward of the softmax
+    wd = w_ref.clone().requires_grad_(True)
+    sc = torch.randn(U, Oc, C, generator=g, dtype=torch.float64, requires_grad=True)
+    sm = torch.softmax(sc, 2)
+    dw = torch.randn(U, Oc, C, generator=g, dtype=torch.float64)
+    sm.backward(dw)
+    ds = H.softmax_bwd(sm.detach().float().cuda(), dw.float().cuda())
+    assert rel_l2(ds, sc.grad) < GRAD_TOL
+    del wd
+
+
+@pytest.mark.parametrize("B,Bc,Fd,T", [(6, 6, 10, 48), (5, 12, 7, 33), (64, 64, 120, 360)])
+def test_clip_kernels(H, B, Bc, Fd, T):
+    g = _gen(B + Bc)
+    est = torch.randn(B, Fd, T, generator=g, dtype=torch.float64, requires_grad=True)
+    cand = torch.randn(Bc, Fd, T, generator=g, dtype=torch.float64) * 2 + 0.3
+    scores_ref = O.clip_scores(est, cand)
+    loss_ref = O.clip_loss(est, cand)
+    loss_ref.backward()
+    K = Fd * T
+    eg, cg = est.detach().float().cuda(), cand.float().cuda()
+    inv = H.clip_inv_norms(cg)
+    assert rel_l2(inv, 1 / (1e-8 + cand.norm(dim=(1, 2)))) < 1e-6
+    part = H.gemm_nt_partials(eg, cg, 1, B, Bc, K, (0, K), (0, K))
+    scores, probs, dscaled, loss = H.clip_ce(part, inv, True, True, True)
+    assert rel_l2(scores, scores_ref) < FWD_TOL
+    assert rel_l2(probs, torch.softmax(scores_ref, 1)) < 1e-5
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0)
+    _, dest, _ = H.conv_nn(cg.view(1, Bc, K), wp, B, 1, 1)
+    assert rel_l2(dest.view(B, Fd, T), est.grad) < GRAD_TOL
+
+
+def test_adam_kernel(H):
+    g = _gen(2)
+    n = 10007
+    p = torch.randn(n, generator=g)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    pg, mg, vg = p.cuda(), m.cuda(), v.cuda()
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 0.1
+        O.adam_step(p, grad, m, v, step)
+        H.adam_step(pg, grad.cuda(), mg, vg, step, 3e-4, 0.9, 0.999, 1e-8)
+    assert rel_l2(pg, p) < 1e-6
+    assert rel_l2(mg, m) < 1e-6 and rel_l2(vg, v) < 1e-6
+
+
+def test_cpu_tensors_are_rejected(H):
+    from brainmagick_amd._lib import BmHipError
+    with pytest.raises(BmHipError):
+        H.glu_fwd(torch.randn(2, 4, 8))
