@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark of the MI355X-native SimpleConv + ClipLoss training step.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = the whole hot path on one synthetic batch already resident in HBM
+(bm/solver.py:343-390): SimpleConv forward, ClipLoss, backward, gradient exchange, fused Adam.
+Workload = BASELINE.json configs[1] (gwilliams2022-shaped MEG: 208 sensors x 360 samples, 120 mel
+features, 27 subjects, batch 256 per GPU, the paper's clip_conv model).  With N > 1 every rank
+processes its own 256 segments (weak scaling), candidates are all-gathered so the negatives pool is
+whole-node (configs[3]) and gradients go through ONE reduce-scatter + all-gather on the flat bucket.
+
+Rank 0 prints ONE JSON line with the driver's contract plus ``roofline`` (dominant kernel, timed
+live with HIP events on the launch stream inside the timed region) and ``cpu_baseline`` (the CPU
+oracle = torch-CPU restatement of the reference, timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from brainmagick_amd import distrib, hip_ops, synthetic  # noqa: E402
+from brainmagick_amd.models import SimpleConv  # noqa: E402
+from brainmagick_amd.solver import Solver  # noqa: E402
+
+# conf/model/clip_conv.yaml:5-38 (the paper model) -- kept literal here: the product does not
+# import the oracle.
+CLIP_CONV = dict(depth=10, kernel_size=3, dilation_growth=2, dilation_period=5, batch_norm=True,
+                 skip=True, gelu=True, glu=2, glu_context=1, glu_glu=True, complex_out=True,
+                 merger=True, merger_pos_dim=2048, merger_channels=270, merger_dropout=0.2,
+                 merger_penalty=0., initial_linear=270, initial_depth=1, subject_layers=True,
+                 subject_layers_dim="input", subject_dim=0)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops_per_segment(C, T, F, hidden=320, merger_ch=270) -> float:
+    """SURVEY.md §8d (de-duplicated merger scores): forward MACs per segment, x2 FLOP, x3 fwd+bwd."""
+    mac = merger_ch * C * T                       # merger apply
+    mac += merger_ch * merger_ch * T * 2          # initial_linear + subject layer
+    cin = merger_ch
+    for k in range(10):
+        mac += hidden * cin * 3 * T
+        cin = hidden
+        if k % 2 == 1:
+            mac += 2 * hidden * hidden * 3 * T    # GLU conv
+    mac += 2 * hidden * hidden * T + 2 * hidden * F * T   # head
+    return 2.0 * 3.0 * mac
+
+
+def cpu_baseline(workload, seconds_budget=20.0):
+    """The CPU oracle (port of the reference path) timed on the host cores, bounded sample."""
+    from oracle import bm_oracle as O
+    B = 16
+    c = synthetic.CONFIGS[workload]
+    sb = synthetic.make_batch(B, c["C"], c["T"], c["F"], c["S"], seed=2036)
+    torch.manual_seed(0)
+    model = SimpleConv(in_channels={"meg": c["C"]}, out_channels=c["F"], hidden={"meg": 320},
+                       n_subjects=c["S"], **CLIP_CONV)
+    oracle = O.OracleModel(model.state_dict(), O.CLIP_CONV_CFG, 320, c["F"])
+    ban = torch.tensor([0.5, 0.5])
+    pos = sb.positions()
+    times = []
+    t_start = time.perf_counter()
+    steps = 0
+    while steps < 2 or (time.perf_counter() - t_start < seconds_budget and steps < 12):
+        t0 = time.perf_counter()
+        oracle.train_step(sb.meg, pos, sb.subject_index, sb.features, ban)
+        times.append(time.perf_counter() - t0)
+        steps += 1
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return dict(value=B / med, unit="segments/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(timed)} train steps of batch {B} ({workload} shapes), median step "
+                       f"{med * 1e3:.0f} ms, torch CPU fp32")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--negatives", default=None, choices=["local", "node"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    distrib.init()
+    rank, world = distrib.rank(), distrib.world_size()
+    if world != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    c = synthetic.CONFIGS[args.workload]
+    B = args.batch
+    negatives = args.negatives or ("node" if world > 1 else "local")
+    torch.manual_seed(2036)
+    model = SimpleConv(in_channels={"meg": c["C"]}, out_channels=c["F"], hidden={"meg": 320},
+                       n_subjects=c["S"], **CLIP_CONV)
+    n_params = sum(p.numel() for p in model.parameters())
+    solver = Solver(model, device=str(dev), negatives=negatives)
+    batch = synthetic.make_config_batch(args.workload, seed=2036 + rank, batch=B).to(dev)
+
+    for _ in range(args.warmup):
+        solver.train_step(batch)
+    timer = hip_ops.KernelTimer()
+    distrib.barrier()
+    torch.cuda.synchronize()
+    hip_ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = solver.train_step(batch)
+    distrib.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    hip_ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    if rank != 0:
+        return
+    ksum = timer.summary()
+    dom = max(ksum, key=lambda k: ksum[k]["avg_ms"] * ksum[k]["launches"])
+    d = ksum[dom]
+    achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
+    seg_flops = algorithmic_flops_per_segment(c["C"], c["T"], c["F"])
+    total_kernel_ms = sum(v["avg_ms"] * v["launches"] for v in ksum.values()) / args.steps
+    out = {
+        "metric": "segments/s, 208-ch x 360-sample SimpleConv + ClipLoss training step",
+        "value": world * B * args.steps / elapsed,
+        "unit": "segments/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: gwilliams2022-shaped MEG C={c['C']} T={c['T']}, "
+                               f"F={c['F']} features, {c['S']} subjects, clip_conv SimpleConv "
+                               f"({n_params} params) + ClipLoss + Adam",
+                   "batch_per_gpu": B, "global_batch": world * B, "negatives": negatives,
+                   "parallelism": f"dp{world}", "final_loss": final_loss,
+                   "step_tflops": seg_flops * B * world * args.steps / elapsed / 1e12},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
+                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,
+                     "algorithmic_flops_per_launch": d["flops_per_launch"],
+                     "mfma_kernels_ms_per_step": total_kernel_ms,
+                     "hbm_roofline_frac_step": (B * 69.2e6 + 108e6) / (PEAK_HBM_GBS * 1e9)
+                     / (elapsed / args.steps) if args.workload == "cfg2" else None},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -40,16 +40,20 @@ extern "C" int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_n
 
 // One wavefront per estimate row b:
 //   scores[b][o] = inv_norm[o] * sum_split part[split][b][o]
-//   loss_row[b]  = logsumexp_o(scores[b]) - scores[b][b]          (F.cross_entropy, target = arange(B))
+//   loss_row[b]  = logsumexp_o(scores[b]) - scores[b][tgt], tgt = b + target_offset
+//                  (F.cross_entropy, target = arange(B); the offset lets a rank point at its own
+//                   block of whole-node gathered candidates without re-ordering them)
 //   probs[b][o]  = softmax_o(scores[b])                            (get_probabilities, losses.py:97-102)
 //   dscaled[b][o]= (probs - [o==b]) / B * inv_norm[o]              (d loss / d(est.cand[o]) )
 __global__ void clip_ce_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ inv_norm,
                                float* __restrict__ scores, float* __restrict__ probs,
-                               float* __restrict__ dscaled, float* __restrict__ loss_row, int B, int Bc) {
+                               float* __restrict__ dscaled, float* __restrict__ loss_row, int B, int Bc,
+                               int target_offset) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
     const long per = (long)B * Bc;
+    const int tgt = b + target_offset;
     float mx = -INFINITY;
     for (int o = lane; o < Bc; o += 64) {
         float s = 0.f;
@@ -68,8 +72,8 @@ __global__ void clip_ce_kernel(const float* __restrict__ part, int nsplit, const
         const float s = scores[(long)b * Bc + o];
         const float p = expf(s - mx) * inv;
         if (probs) probs[(long)b * Bc + o] = p;
-        if (dscaled) dscaled[(long)b * Bc + o] = (p - (o == b ? 1.f : 0.f)) / (float)B * inv_norm[o];
-        if (o == b && loss_row) loss_row[b] = lse - s;
+        if (dscaled) dscaled[(long)b * Bc + o] = (p - (o == tgt ? 1.f : 0.f)) / (float)B * inv_norm[o];
+        if (o == tgt && loss_row) loss_row[b] = lse - s;
     }
 }
 
@@ -85,14 +89,15 @@ __global__ void mean_kernel(const float* __restrict__ x, int n, float* __restric
 
 extern "C" int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores,
                           float* probs, float* dscaled, float* loss_row, float* loss, int B, int Bc,
-                          void* stream) {
+                          int target_offset, void* stream) {
     BM_REQUIRE(part && inv_norm && scores, "clip_ce: null pointer");
-    BM_REQUIRE(B <= Bc || !loss, "clip_ce: need at least as many targets as estimates");
+    BM_REQUIRE(!loss || (target_offset >= 0 && target_offset + B <= Bc),
+               "clip_ce: need at least as many targets as estimates");
     BM_REQUIRE(!loss || loss_row, "clip_ce: loss needs loss_row scratch");
     if (B == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(clip_ce_kernel, dim3((B + 3) / 4), dim3(256), 0, s, part, nsplit, inv_norm, scores,
-                       probs, dscaled, loss_row, B, Bc);
+                       probs, dscaled, loss_row, B, Bc, target_offset);
     if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, loss_row, B, loss);
     return bm_check_launch("clip_ce");
 }

@@ -108,8 +108,6 @@ class ConvBNActFn(torch.autograd.Function):
                                     act=act, leak=leak, want_pre=needs_grad)
         ctx.save_for_backward(x, weight, pre, scale, shift, mean, invstd)
         ctx.cfg = (training, dil, act, leak, residual, KS, bias is not None)
-        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches)
-                                      if t is not None])
         return out
 
     @staticmethod
@@ -127,8 +125,6 @@ class ConvBNActFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight), Cin, KS, dil,
                                  res=dout if residual else None)
-        elif residual:
-            dx = None
         dw = H.gemm_nt(dy, x, x.shape[0], M, Cin, x.shape[2], KS, dil).view(weight.shape) \
             if ctx.needs_input_grad[1] else None
         return (dx, dw, dbias, dgamma, dbeta) + (None,) * 10
@@ -245,14 +241,15 @@ class ClipLossFn(torch.autograd.Function):
     MFMA GEMM dEst = dScores . cand."""
 
     @staticmethod
-    def forward(ctx, estimate, candidate):
+    def forward(ctx, estimate, candidate, target_offset: int = 0):
         estimate, candidate = _c(estimate), _c(candidate)
         B, Bc = estimate.shape[0], candidate.shape[0]
         K = estimate.numel() // B
         assert candidate.numel() // Bc == K
         inv = H.clip_inv_norms(candidate)
         part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
-        scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True)
+        scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True,
+                                             target_offset=target_offset)
         ctx.save_for_backward(candidate, dscaled)
         ctx.shape = estimate.shape
         ctx.mark_non_differentiable(scores)
@@ -268,7 +265,7 @@ class ClipLossFn(torch.autograd.Function):
         K = candidate.numel() // Bc
         wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=_c(dloss).view(1))
         _, dest, _ = H.conv_nn(candidate.view(1, Bc, K), wp, B, 1, 1)
-        return dest.view(ctx.shape), None
+        return dest.view(ctx.shape), None, None
 
 
 def clip_scores(estimate, candidate, want_probs=False):

@@ -16,6 +16,43 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 BKC = 16
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the MFMA kernels, on the stream they are launched on (the
+    current torch stream).  ``bench.py`` installs one to measure the dominant kernel's average
+    launch duration live inside the timed region; cost = two event records per launch."""
+
+    def __init__(self):
+        self.records: tp.List[tp.Tuple[str, float, torch.cuda.Event, torch.cuda.Event]] = []
+
+    def launch(self, name: str, flops: float, fn):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        out = fn()
+        end.record()
+        self.records.append((name, flops, start, end))
+        return out
+
+    def summary(self) -> tp.Dict[str, tp.Dict[str, float]]:
+        """name -> {launches, avg_ms, flops_per_launch}; call after a device synchronize."""
+        agg: tp.Dict[str, tp.List[float]] = {}
+        for name, flops, start, end in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += start.elapsed_time(end)
+            a[2] += flops
+        return {k: dict(launches=v[0], avg_ms=v[1] / v[0], flops_per_launch=v[2] / v[0])
+                for k, v in agg.items()}
+
+
+_timer: tp.Optional[KernelTimer] = None
+
+
+def set_kernel_timer(timer: tp.Optional[KernelTimer]):
+    global _timer
+    _timer = timer
+
+
 def _p(t: tp.Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -83,11 +120,17 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))
-    check(lib().bm_conv1d_nn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
-                             _p(_opt(bias, "bias")), _p(_opt(scale, "scale")),
-                             _p(_opt(shift, "shift")), _p(res), M * T, _p(y_pre), _p(y_out), M * T,
-                             _p(stats), B, Cin, M, T, KS, dil, act, leak, _stream()),
-          "bm_conv1d_nn")
+    def launch():
+        check(lib().bm_conv1d_nn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
+                                 _p(_opt(bias, "bias")), _p(_opt(scale, "scale")),
+                                 _p(_opt(shift, "shift")), _p(res), M * T, _p(y_pre), _p(y_out),
+                                 M * T, _p(stats), B, Cin, M, T, KS, dil, act, leak, _stream()),
+              "bm_conv1d_nn")
+    if _timer is not None:
+        _timer.launch(f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>", 2.0 * B * T * M * Cin * KS,
+                      launch)
+    else:
+        launch()
     return y_pre, y_out, stats
 
 
@@ -129,9 +172,15 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = out
     else:
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
-    check(lib().bm_gemm_nt(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
-                           _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)),
-                           _p(part), S, G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
+    def launch():
+        check(lib().bm_gemm_nt(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
+                               _p(_opt(order, "order", torch.int32)),
+                               _p(_opt(seg, "seg", torch.int32)), _p(part), S, G, M, Cn, T, KS, dil,
+                               nsplit, _stream()), "bm_gemm_nt")
+    if _timer is not None:
+        _timer.launch(f"gemm_nt_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS, launch)
+    else:
+        launch()
     if part is not out:
         check(lib().bm_reduce_splits(_p(part), _p(out), G, nsplit, M, Cn, KS, *out_strides,
                                      _stream()), "bm_reduce_splits")
@@ -288,7 +337,8 @@ def clip_inv_norms(cand: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False):
+def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
+            target_offset: int = 0):
     """part [nsplit][B][B'] -> (scores, probs|None, dscaled|None, loss|None)."""
     _req(part, "clip_ce.part")
     nsplit, B, Bc = part.shape
@@ -299,7 +349,7 @@ def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False):
     loss_row = torch.empty(B, device=dev, dtype=torch.float32) if want_loss else None
     loss = torch.empty((), device=dev, dtype=torch.float32) if want_loss else None
     check(lib().bm_clip_ce(_p(part), nsplit, _p(_req(inv_norm, "inv_norm")), _p(scores), _p(probs),
-                           _p(dscaled), _p(loss_row), _p(loss), B, Bc, _stream()), "bm_clip_ce")
+                           _p(dscaled), _p(loss_row), _p(loss), B, Bc, target_offset, _stream()), "bm_clip_ce")
     return scores, probs, dscaled, loss
 
 

@@ -1,0 +1,85 @@
+"""Host-side mirror of ``bm/losses.py``'s ``ClipLoss`` (the contrastive head of the hot path):
+same constructor, ``forward`` / ``get_scores`` / ``get_probabilities`` / ``trim_samples`` with the
+reference's argument meaning and assertion behaviour; the contraction over K = F*T, the candidate
+norms, the row softmax / cross-entropy and the backward GEMM are libbmhip kernels.
+"""
+import torch
+
+from . import functional as BF
+
+
+class ClipLoss(torch.nn.Module):
+    """CLIP contrastive loss (bm/losses.py:29-114).
+
+    ``linear`` is accepted and, exactly like in the reference, never applied: the reference sets
+    ``self.linear = None`` (losses.py:35) and only tests that attribute (losses.py:82)."""
+
+    def __init__(self, linear=None, twin=True, pool=False, tmin=None, tmax=None,
+                 tmin_train=None, tmax_train=None, dset_args=None, center=False):
+        super().__init__()
+        self.linear = None
+        self.pool = pool
+        self.center = center
+        if linear is not None:
+            self.linear_est = torch.nn.LazyLinear(linear)
+            self.linear_gt = self.linear_est if twin else torch.nn.LazyLinear(linear)
+        self.tmin = tmin
+        self.tmax = tmax
+        self.tmin_train = tmin_train
+        self.tmax_train = tmax_train
+        self.dset_args = dset_args
+
+    def trim_samples(self, estimates, candidates):
+        """Crop both [B, C, T] tensors to the samples between (tmin, tmax) seconds, counted from
+        ``dset_args.tmin`` at ``dset_args.sample_rate`` (losses.py:50-75)."""
+        use_train = self.training and (self.tmin_train is not None or self.tmax_train is not None)
+        tmin, tmax = (self.tmin_train, self.tmax_train) if use_train else (self.tmin, self.tmax)
+        lo, hi = 0, estimates.shape[-1]
+        if tmin is not None or tmax is not None:
+            assert self.dset_args is not None
+            assert self.dset_args.tmin is not None
+            origin, rate = self.dset_args.tmin, self.dset_args.sample_rate
+            if tmin is not None:
+                assert tmin >= origin, 'clip.tmin should be above dset.tmin'
+                lo = int((-origin + tmin) * rate)
+            if tmax is not None:
+                hi = int((-origin + tmax) * rate)
+        return estimates[..., lo:hi], candidates[..., lo:hi]
+
+    def _prepare(self, estimates, candidates):
+        estimates, candidates = self.trim_samples(estimates, candidates)
+        # pool / center are off in every configuration of the paper (conf/config.yaml:56-64); they
+        # are cheap pre-reductions done with torch ops on the GPU before the HIP contraction.
+        if self.pool:
+            estimates = estimates.mean(dim=2, keepdim=True)
+            candidates = candidates.mean(dim=2, keepdim=True)
+        if self.center:
+            estimates = estimates - estimates.mean(dim=(1, 2), keepdim=True)
+            candidates = candidates - candidates.mean(dim=(1, 2), keepdim=True)
+        if not estimates.is_cuda:
+            raise RuntimeError("brainmagick_amd.ClipLoss runs on the MI355X HIP path only "
+                               "(no CPU fallback)")
+        return estimates.contiguous(), candidates.contiguous()
+
+    def get_scores(self, estimates: torch.Tensor, candidates: torch.Tensor):
+        """[B, C, T] x [B', C, T] -> [B, B'] matching scores (losses.py:77-95)."""
+        estimates, candidates = self._prepare(estimates, candidates)
+        if torch.is_grad_enabled() and estimates.requires_grad:
+            return BF.ClipLossFn.apply(estimates, candidates)[1]
+        return BF.clip_scores(estimates, candidates)
+
+    def get_probabilities(self, estimates, candidates):
+        """[B, B'] row-softmax of the scores (losses.py:97-102)."""
+        estimates, candidates = self._prepare(estimates, candidates)
+        return BF.clip_scores(estimates.detach(), candidates.detach(), want_probs=True)
+
+    def forward(self, estimate, candidate, mask=None, target_offset: int = 0):
+        """The first B candidates are the targets of the B estimates, the remaining B'-B are only
+        negatives (losses.py:104-114).  ``target_offset`` (extension, default 0 = reference
+        behaviour) shifts the targets to candidates [offset, offset+B): a data-parallel rank uses
+        it to point at its own block of the whole-node gathered candidates."""
+        assert mask.all(), "mask is not supported for now"
+        assert estimate.size(0) + target_offset <= candidate.size(0), \
+            "need at least as many targets as estimates"
+        estimate, candidate = self._prepare(estimate, candidate)
+        return BF.ClipLossFn.apply(estimate, candidate, target_offset)[0]

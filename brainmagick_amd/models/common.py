@@ -1,0 +1,312 @@
+"""Host-side mirror of ``bm/models/common.py`` for the hot path: same class names, constructor
+arguments, parameter / buffer names (``state_dict`` keys) and error behaviour as the reference,
+with every tensor op replaced by libbmhip kernels (``brainmagick_amd.functional``).
+
+Modules only hold parameters and sequence the HIP ops; they raise on CPU tensors (no fallback).
+"""
+from functools import partial
+import math
+import typing as tp
+
+import torch
+from torch import nn
+
+from .. import functional as BF
+from .. import hip_ops as H
+
+
+class ScaledEmbedding(nn.Module):
+    """bm/models/common.py:29-43.  Tiny [n_subjects, dim] lookup (host-side plumbing)."""
+    def __init__(self, num_embeddings: int, embedding_dim: int, scale: float = 10.):
+        super().__init__()
+        self.embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self.embedding.weight.data /= scale
+        self.scale = scale
+
+    @property
+    def weight(self):
+        return self.embedding.weight * self.scale
+
+    def forward(self, x):
+        return self.embedding(x) * self.scale
+
+
+class SubjectLayers(nn.Module):
+    """Per subject linear layer (bm/models/common.py:45-62); parameter ``weights`` [S, C, D]."""
+    def __init__(self, in_channels: int, out_channels: int, n_subjects: int, init_id: bool = False):
+        super().__init__()
+        self.weights = nn.Parameter(torch.randn(n_subjects, in_channels, out_channels))
+        if init_id:
+            assert in_channels == out_channels
+            self.weights.data[:] = torch.eye(in_channels)[None]
+        self.weights.data *= 1 / in_channels**0.5
+
+    def forward(self, x, subjects):
+        return BF.SubjectLayersFn.apply(x, self.weights, subjects)
+
+    def __repr__(self):
+        S, C, D = self.weights.shape
+        return f"SubjectLayers({C}, {D}, {S})"
+
+
+class _Activation(nn.Module):
+    """Marker module standing where the reference puts nn.GELU / nn.ReLU / nn.LeakyReLU
+    (it keeps the ``nn.Sequential`` indices, hence the state_dict keys, identical); the
+    activation itself runs in the epilogue of the preceding HIP op."""
+    def __init__(self, kind: str, leak: float = 0.):
+        super().__init__()
+        self.kind = kind
+        self.leak = leak
+
+    @property
+    def code(self) -> int:
+        return BF.ACT_CODES[self.kind]
+
+    def extra_repr(self):
+        return self.kind + (f", {self.leak}" if self.kind == "leaky" else "")
+
+
+def make_activation(gelu: bool, relu_leakiness: float) -> tp.Callable[[], _Activation]:
+    """Activation choice of bm/models/simpleconv.py:85-90."""
+    if gelu:
+        return partial(_Activation, "gelu")
+    if relu_leakiness:
+        return partial(_Activation, "leaky", relu_leakiness)
+    return partial(_Activation, "relu")
+
+
+class _GLU(nn.Module):
+    """Marker for nn.GLU(dim=1) (fused in GLUConvFn)."""
+
+
+class ConvSequence(nn.Module):
+    """bm/models/common.py:79-151.  Same constructor; builds the same ``sequence`` / ``glus``
+    module lists (so ``sequence.k.0`` is the conv, ``sequence.k.1`` the BatchNorm1d, ``glus.k.0``
+    the GLU conv) but runs each layer as fused HIP kernels."""
+
+    def __init__(self, channels: tp.Sequence[int], kernel: int = 4, dilation_growth: int = 1,
+                 dilation_period: tp.Optional[int] = None, stride: int = 2,
+                 dropout: float = 0.0, leakiness: float = 0.0, groups: int = 1,
+                 decode: bool = False, batch_norm: bool = False, dropout_input: float = 0,
+                 skip: bool = False, scale: tp.Optional[float] = None, rewrite: bool = False,
+                 activation_on_last: bool = True, post_skip: bool = False, glu: int = 0,
+                 glu_context: int = 0, glu_glu: bool = True, activation: tp.Any = None) -> None:
+        super().__init__()
+        unsupported = dict(stride=stride != 1, dropout=bool(dropout), groups=groups != 1,
+                           decode=decode, dropout_input=bool(dropout_input),
+                           scale=scale is not None, rewrite=rewrite, post_skip=post_skip)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(
+                f"ConvSequence options {bad} are outside the MI355X hot path (unused by the paper's "
+                "grids, SURVEY.md §2.2)")
+        if kernel % 2 != 1:
+            raise NotImplementedError("only odd kernels ('same' padding) are on the hot path")
+        dilation = 1
+        channels = tuple(channels)
+        self.skip = skip
+        self.sequence = nn.ModuleList()
+        self.glus = nn.ModuleList()
+        if activation is None:
+            activation = partial(_Activation, "leaky", leakiness)
+        self._plan: tp.List[dict] = []
+        for k, (chin, chout) in enumerate(zip(channels[:-1], channels[1:])):
+            layers: tp.List[nn.Module] = []
+            is_last = k == len(channels) - 2
+            if dilation_period and (k % dilation_period) == 0:
+                dilation = 1
+            pad = kernel // 2 * dilation
+            layers.append(nn.Conv1d(chin, chout, kernel, 1, pad, dilation=dilation))
+            plan = dict(dilation=dilation, act=None, bn=False, glu=None)
+            dilation *= dilation_growth
+            if activation_on_last or not is_last:
+                if batch_norm:
+                    layers.append(nn.BatchNorm1d(num_features=chout))
+                    plan["bn"] = True
+                act = activation()
+                layers.append(act)
+                plan["act"] = act
+            self.sequence.append(nn.Sequential(*layers))
+            if glu and (k + 1) % glu == 0:
+                ch = 2 * chout if glu_glu else chout
+                act = _GLU() if glu_glu else activation()
+                self.glus.append(
+                    nn.Sequential(
+                        nn.Conv1d(chout, ch, 1 + 2 * glu_context, padding=glu_context), act))
+                plan["glu"] = act
+            else:
+                self.glus.append(None)
+            self._plan.append(plan)
+
+    def forward(self, x: tp.Any) -> tp.Any:
+        for module_idx, module in enumerate(self.sequence):
+            plan = self._plan[module_idx]
+            conv = module[0]
+            act = plan["act"]
+            code = act.code if act is not None else H.ACT_NONE
+            leak = act.leak if act is not None else 0.
+            residual = self.skip and conv.in_channels == conv.out_channels
+            if plan["bn"]:
+                bn = module[1]
+                x = BF.ConvBNActFn.apply(
+                    x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                    bn.num_batches_tracked, self.training, plan["dilation"], code, leak, residual,
+                    bn.momentum, bn.eps)
+            else:
+                y = BF.Conv1dFn.apply(x, conv.weight, conv.bias, plan["dilation"], code, leak, False)
+                x = _AddFn.apply(y, x) if residual else y
+            glu = self.glus[module_idx]
+            if glu is not None:
+                gconv = glu[0]
+                if isinstance(glu[1], _GLU):
+                    x = BF.GLUConvFn.apply(x, gconv.weight, gconv.bias)
+                else:
+                    x = BF.Conv1dFn.apply(x, gconv.weight, gconv.bias, 1, glu[1].code, glu[1].leak,
+                                          False)
+        return x
+
+
+class _AddFn(torch.autograd.Function):
+    """x + old_x for the (rare) skip layer without BatchNorm, as an affine_act_res launch."""
+    @staticmethod
+    def forward(ctx, y, res):
+        return H.affine_act_res(y.contiguous(), None, None, res.contiguous(), H.ACT_NONE)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, dout
+
+
+class PositionGetter:
+    """bm/models/common.py:187-236.  Per-recording 2-D sensor layout, normalised to [0,1]^2;
+    sensors missing from the layout (or padded channels) get INVALID = -0.1.
+
+    ``mne`` is imported lazily and only when a recording carries a real ``mne_info``; recordings
+    that already expose a ``layout`` tensor (synthetic data, pre-extracted layouts) are used as is.
+    MI355X-first addition: ``get_unique_layouts`` de-duplicates the layouts of a batch so the
+    attention weights are computed once per layout, not once per segment."""
+    INVALID = -0.1
+
+    def __init__(self) -> None:
+        self._cache: tp.Dict[int, torch.Tensor] = {}
+        self._invalid_names: tp.Set[str] = set()
+
+    def get_recording_layout(self, recording) -> torch.Tensor:
+        index = recording.recording_index
+        if index in self._cache:
+            return self._cache[index]
+        if getattr(recording, "layout", None) is not None:
+            positions = torch.as_tensor(recording.layout, dtype=torch.float32)
+        else:
+            positions = self._layout_from_mne(recording.mne_info)
+        self._cache[index] = positions
+        return positions
+
+    def _layout_from_mne(self, info) -> torch.Tensor:
+        """2-D layout of the channels named in an ``mne.Info`` (what mne.find_layout knows about),
+        min-max normalised per axis over the channels that were found; the rest stay INVALID."""
+        import mne  # only needed with real recordings
+        layout = mne.find_layout(info)
+        slot_of = {name: k for k, name in enumerate(layout.names)}
+        found = [(ch, slot_of[name.rsplit("-", 1)[0]]) for ch, name in enumerate(info.ch_names)
+                 if name.rsplit("-", 1)[0] in slot_of]
+        self._invalid_names.update(name.rsplit("-", 1)[0] for name in info.ch_names
+                                   if name.rsplit("-", 1)[0] not in slot_of)
+        positions = torch.full((len(info.ch_names), 2), self.INVALID)
+        if found:
+            channels, slots = zip(*found)
+            xy = torch.as_tensor(layout.pos[list(slots), :2], dtype=torch.float64)
+            lo, hi = xy.min(0).values, xy.max(0).values
+            positions[list(channels)] = ((xy - lo) / (hi - lo)).float()
+        return positions
+
+    def get_positions(self, batch):
+        """[B, C, 2] like the reference (common.py:225-233)."""
+        meg = batch.meg
+        B, C, T = meg.shape
+        positions = torch.full((B, C, 2), self.INVALID, device=meg.device)
+        for idx in range(len(batch)):
+            rec_pos = self.get_recording_layout(batch._recordings[idx])
+            positions[idx, :len(rec_pos)] = rec_pos.to(meg.device)
+        return positions
+
+    def get_unique_layouts(self, batch, n_channels: int, device):
+        """-> (positions_u [U, C, 2] on device, layout_index [B] int64 on device)."""
+        slots: tp.Dict[int, int] = {}
+        rows: tp.List[torch.Tensor] = []
+        index: tp.List[int] = []
+        for idx in range(len(batch)):
+            rec = batch._recordings[idx]
+            key = rec.recording_index
+            if key not in slots:
+                slots[key] = len(rows)
+                pos = torch.full((n_channels, 2), self.INVALID)
+                rec_pos = self.get_recording_layout(rec)
+                pos[:len(rec_pos)] = rec_pos
+                rows.append(pos)
+            index.append(slots[key])
+        positions_u = torch.stack(rows).to(device)
+        layout_index = torch.tensor(index, dtype=torch.int64).to(device)
+        return positions_u, layout_index
+
+    def is_invalid(self, positions):
+        return (positions == self.INVALID).all(dim=-1)
+
+
+class FourierEmb(nn.Module):
+    """bm/models/common.py:239-271."""
+    def __init__(self, dimension: int = 256, margin: float = 0.2):
+        super().__init__()
+        n_freqs = (dimension // 2)**0.5
+        assert int(n_freqs ** 2 * 2) == dimension
+        self.dimension = dimension
+        self.margin = margin
+
+    def forward(self, positions):
+        return H.fourier_emb(positions.contiguous(), self.dimension, self.margin)
+
+
+class ChannelMerger(nn.Module):
+    """bm/models/common.py:312-362; parameter ``heads`` [chout, pos_dim]."""
+    def __init__(self, chout: int, pos_dim: int = 256,
+                 dropout: float = 0, usage_penalty: float = 0.,
+                 n_subjects: int = 200, per_subject: bool = False):
+        super().__init__()
+        assert pos_dim % 4 == 0
+        if per_subject or usage_penalty > 0.:
+            raise NotImplementedError("merger_per_subject / merger_penalty are outside the MI355X "
+                                      "hot path (unused by the paper's grids, SURVEY.md §2.2)")
+        self.position_getter = PositionGetter()
+        self.per_subject = per_subject
+        self.heads = nn.Parameter(torch.randn(chout, pos_dim, requires_grad=True))
+        self.heads.data /= pos_dim ** 0.5
+        self.dropout = dropout
+        self.embedding = FourierEmb(pos_dim)
+        self.usage_penalty = usage_penalty
+        self._penalty = torch.tensor(0.)
+        # test hook: parity tests inject the ban centre instead of drawing torch.rand(2) on the
+        # device generator (CPU and GPU RNG streams differ)
+        self.ban_center_override: tp.Optional[torch.Tensor] = None
+
+    @property
+    def training_penalty(self):
+        return self._penalty.to(next(self.parameters()).device)
+
+    def forward(self, meg, batch):
+        B, C, T = meg.shape
+        positions_u, layout_index = self.position_getter.get_unique_layouts(batch, C, meg.device)
+        ban_center, radius = None, 0.
+        if self.training and self.dropout:
+            if self.ban_center_override is not None:
+                ban_center = self.ban_center_override.to(meg.device, torch.float32)
+            else:
+                ban_center = torch.rand(2, device=meg.device)        # common.py:343
+            radius = float(self.dropout)
+        return BF.ChannelMergerFn.apply(meg, self.heads, positions_u, layout_index, ban_center,
+                                        radius)
+
+
+def pad_multiple(x: torch.Tensor, base: int):
+    length = x.shape[-1]
+    target = math.ceil(length / base) * base
+    return torch.nn.functional.pad(x, (0, target - length))

@@ -1,0 +1,96 @@
+"""Host-side mirror of the hot loop of ``bm/solver.py``: ``_process_batch`` (bm/solver.py:230-321)
+and the per-batch body of ``_run_one_epoch`` (bm/solver.py:343-390), for the decode task with the
+CLIP loss -- the path BASELINE.json names.  Everything around it in the reference (flashy stages,
+checkpoint commit, tensorboard, dataset construction) stays the reference's business.
+
+Differences to the reference, all MI355X-motivated and opt-in/neutral:
+  * gradients / optimizer: ONE flat bucket -> reduce-scatter + fused Adam on the shard + all-gather
+    (``distrib.sharded_step``) instead of ``flashy.distrib.sync_model`` + ``optimizer.step()``;
+  * ``negatives="node"``: candidates of all ranks are all-gathered over xGMI while the encoder runs
+    (``negatives="local"`` reproduces the reference: negatives only within a GPU, README.md:139-143);
+  * the loss stays on the device (no per-step ``.item()`` sync); read it at print points.
+"""
+import typing as tp
+
+import torch
+
+from . import distrib
+from .losses import ClipLoss
+from .optim import FlatAdam
+
+
+class Solver:
+    def __init__(self, model: torch.nn.Module, loss: tp.Optional[ClipLoss] = None,
+                 optimizer: tp.Optional[FlatAdam] = None, device: str = "cuda",
+                 offset_meg_ms: float = 0., sample_rate: float = 120., negatives: str = "local",
+                 lr: float = 3e-4, betas=(0.9, 0.999)):
+        assert negatives in ("local", "node")
+        self.device = torch.device(device)
+        self.model = model.to(self.device)
+        self.loss = (loss or ClipLoss()).to(self.device)
+        world = distrib.world_size()
+        if optimizer is None:
+            params = list(self.model.parameters()) + list(self.loss.parameters())
+            optimizer = FlatAdam(params, lr=lr, betas=betas, pad_to=max(world, 1) * 4)
+        self.optimizer = optimizer
+        self.offset_meg_ms = offset_meg_ms
+        self.sample_rate = sample_rate
+        self.negatives = negatives
+        self._gather = distrib.CandidateGather() if negatives == "node" else None
+
+    # -- bm/solver.py:230-321 ------------------------------------------------------------------
+    def _process_batch(self, batch, training: bool = False):
+        batch = batch.to(self.device)
+        reject_mask = torch.ones(len(batch.meg), dtype=torch.bool, device=self.device)
+        meg = batch.meg
+        features = batch.features
+        features_mask = batch.features_mask
+        if len(meg) == 0:
+            return None, None, None, None
+        if self.offset_meg_ms:
+            # bm/solver.py:262-274: brain responses lag the audio by ~150 ms
+            offset = int(self.offset_meg_ms / 1000 * self.sample_rate)
+            meg = meg[..., offset:]
+            features = features[..., :-offset]
+            features_mask = features_mask[..., :-offset]
+        if self._gather is not None:
+            # candidates do not depend on the model: start the xGMI all-gather before the encoder
+            self._gather.start(features.contiguous())
+        inputs = dict(meg=meg.contiguous())
+        estimate = self.model(inputs, batch)
+        return estimate, features, features_mask, reject_mask
+
+    # -- bm/solver.py:343-390 (one iteration) -----------------------------------------------------
+    def train_step(self, batch) -> torch.Tensor:
+        self.model.train(True)
+        self.loss.train(True)
+        estimate, output, features_mask, _ = self._process_batch(batch, training=True)
+        target_offset = 0
+        if self._gather is not None:
+            output, target_offset = self._gather.wait()
+        loss = self.loss(estimate, output, features_mask, target_offset=target_offset)
+        # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path
+        # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
+        self.optimizer.zero_grad()
+        loss.backward()
+        distrib.sharded_step(self.optimizer)
+        return loss.detach()
+
+    @torch.no_grad()
+    def eval_step(self, batch) -> torch.Tensor:
+        self.model.train(False)
+        self.loss.train(False)
+        estimate, output, features_mask, _ = self._process_batch(batch, training=False)
+        target_offset = 0
+        if self._gather is not None:
+            output, target_offset = self._gather.wait()
+        return self.loss(estimate, output, features_mask, target_offset=target_offset)
+
+    @torch.no_grad()
+    def predict(self, batch):
+        """(estimate, candidates) for retrieval evaluation (bm/wer.py:52, run_eval_probs.py:102)."""
+        self.model.train(False)
+        estimate, output, _, _ = self._process_batch(batch, training=False)
+        if self._gather is not None:
+            self._gather.wait()
+        return estimate, output

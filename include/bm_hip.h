@@ -100,7 +100,8 @@ int bm_softmax_bwd(const float* w, const float* dw, float* ds, long rows, int C,
 /* ---- ClipLoss (clip.hip)  bm/losses.py:77-114 ---- */
 int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_norm, void* stream);
 int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores, float* probs,
-               float* dscaled, float* loss_row, float* loss, int B, int Bc, void* stream);
+               float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
+               void* stream);
 
 /* ---- fused Adam on the flat bucket (adam.hip)  torch.optim.Adam @ bm/train.py:118-119 ---- */
 int bm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,

@@ -1,0 +1,176 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol,
+the modules keep the reference's state_dict contract, the product refuses to run without the GPU
+(no fallback), and the data-parallel exchange is correct at world_size 2 on gloo."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+from helpers import Golden, MODEL_FIXTURES
+from oracle import bm_oracle as O
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from brainmagick_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 30
+    handle = _lib.lib()
+    for name in protos:
+        assert hasattr(handle, name), name
+    assert handle.bm_version() >= 100
+    # geometry helpers are pure host functions: callable without a GPU
+    assert handle.bm_conv_mpad(320) == 320 and handle.bm_conv_mpad(270) == 288
+    assert handle.bm_conv_stats_tiles(256, 360) == 768
+    assert handle.bm_bwd_nsplit(256) == 8
+
+
+def test_header_cites_reference_for_every_group():
+    text = (ROOT / "include" / "bm_hip.h").read_text()
+    assert len(re.findall(r"(?:bm/)?[\w/]+\.py:\d+", text)) >= 10
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_state_dict_contract(name):
+    """Same keys, shapes and dtypes as the reference's state_dict; strict load works; same-seed
+    construction reproduces the reference initialisation bit for bit."""
+    from brainmagick_amd.models import SimpleConv
+    g = Golden(name)
+    meta = g.meta
+    sd0 = g.group("sd0")
+    seed = 2036 + sum(map(ord, name))            # tests/golden/make_golden.py
+    torch.manual_seed(seed)
+    model = SimpleConv(in_channels={"meg": meta["C"]}, out_channels=meta["F"],
+                       hidden={"meg": meta["hidden"]}, n_subjects=meta["S"], **meta["cfg"])
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(sd0.keys())
+    for k in sd:
+        assert sd[k].shape == sd0[k].shape and sd[k].dtype == sd0[k].dtype, k
+        if "running_" not in k and ".1.weight" not in k and ".1.bias" not in k:
+            assert torch.equal(sd[k], sd0[k]), k   # BN tensors were randomised after construction
+    model.load_state_dict(sd0, strict=True)
+
+
+def test_unsupported_options_raise():
+    from brainmagick_amd.models import SimpleConv
+    base = dict(in_channels={"meg": 8}, out_channels=4, hidden={"meg": 8})
+    for kw in (dict(n_fft=16), dict(dual_path=1), dict(dropout=0.1), dict(rewrite=True),
+               dict(merger=True, merger_penalty=0.1), dict(groups=2)):
+        with pytest.raises(NotImplementedError):
+            SimpleConv(**{**base, "in_channels": {"meg": 8}}, **kw)
+    with pytest.raises(ValueError):
+        SimpleConv(in_channels={"meg": 8}, out_channels=4, hidden={"eeg": 8})
+
+
+def test_no_cpu_fallback():
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.losses import ClipLoss
+    from brainmagick_amd.optim import FlatAdam
+    from brainmagick_amd import synthetic
+    model = SimpleConv(in_channels={"meg": 8}, out_channels=4, hidden={"meg": 8}, subject_dim=0)
+    sb = synthetic.make_batch(2, 8, 16, 4, 3)
+    with pytest.raises(RuntimeError):
+        model({"meg": sb.meg}, sb)
+    with pytest.raises(RuntimeError):
+        ClipLoss()(torch.randn(2, 4, 16), torch.randn(2, 4, 16), torch.ones(2, 1, 16, dtype=torch.bool))
+    with pytest.raises(RuntimeError):
+        FlatAdam(model.parameters())
+
+
+def test_clip_loss_asserts_like_reference():
+    from brainmagick_amd.losses import ClipLoss
+    loss = ClipLoss()
+    with pytest.raises(AssertionError):
+        loss(torch.randn(3, 2, 4), torch.randn(2, 2, 4), torch.ones(3, 1, 4, dtype=torch.bool))
+    with pytest.raises(AssertionError):
+        loss(torch.randn(2, 2, 4), torch.randn(2, 2, 4), torch.zeros(2, 1, 4, dtype=torch.bool))
+    assert ClipLoss(linear=16).linear is None        # accepted, never applied (losses.py:35,82)
+
+
+def test_product_never_imports_oracle():
+    for path in (ROOT / "brainmagick_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, path
+
+
+def test_synthetic_batches_are_seeded_and_shaped():
+    from brainmagick_amd import synthetic
+    a = synthetic.make_config_batch("cfg2", batch=4)
+    b = synthetic.make_config_batch("cfg2", batch=4)
+    assert torch.equal(a.meg, b.meg) and a.meg.shape == (4, 208, 360)
+    assert a.features.shape == (4, 120, 360) and a.meg.abs().max() <= 20
+    m = synthetic.make_config_batch("cfg5", batch=16)
+    pos = m.positions()
+    eeg = [i for i, r in enumerate(m._recordings) if len(r.layout) == 128]
+    assert eeg, "mixed batch should contain EEG segments"
+    assert (pos[eeg[0], 128:] == synthetic.INVALID).all() and (m.meg[eeg[0], 128:] == 0).all()
+    assert (m.subject_index[eeg] < 19).all()
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from brainmagick_amd import distrib
+from oracle import bm_oracle as O
+
+class CpuFlatAdam:
+    """Test double with FlatAdam's interface, arithmetic = the oracle's adam_step."""
+    def __init__(self, n, pad_to):
+        self.padded = (n + pad_to - 1) // pad_to * pad_to
+        g = torch.Generator().manual_seed(0)
+        self.flat_param = torch.randn(self.padded, generator=g)
+        self.flat_grad = torch.zeros(self.padded)
+        self.m = torch.zeros(self.padded); self.v = torch.zeros(self.padded); self.t = 0
+    def step(self, shard=None, grad_scale=1.0):
+        self.t += 1
+        lo, hi = shard if shard else (0, self.padded)
+        O.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi] * grad_scale, self.m[lo:hi],
+                    self.v[lo:hi], self.t)
+
+distrib.init("gloo")
+r, w = distrib.rank(), distrib.world_size()
+assert w == 2
+opt = CpuFlatAdam(1001, pad_to=w * 4)
+ref = CpuFlatAdam(1001, pad_to=w * 4)
+for it in range(3):
+    grads = [torch.randn(opt.padded, generator=torch.Generator().manual_seed(100 * it + k)) for k in range(w)]
+    opt.flat_grad.copy_(grads[r])
+    distrib.sharded_step(opt)
+    ref.flat_grad.copy_(O.sync_gradients_reference([[g] for g in grads])[0])
+    ref.step()
+assert torch.allclose(opt.flat_param, ref.flat_param, rtol=1e-6, atol=1e-7), (opt.flat_param - ref.flat_param).abs().max()
+# candidate all-gather: rank-ordered, own block at rank*B
+gather = distrib.CandidateGather()
+cand = torch.full((3, 2, 5), float(r))
+gather.start(cand)
+out, off = gather.wait()
+assert out.shape == (6, 2, 5) and off == 3 * r
+assert (out[off:off + 3] == r).all() and (out[3 * (1 - r):3 * (1 - r) + 3] == 1 - r).all()
+m = distrib.average_metrics({"loss": float(r + 1)}, count=r + 1)
+assert abs(m["loss"] - (1 * 1 + 2 * 2) / 3) < 1e-9
+# BN buffers are averaged
+bn = torch.nn.BatchNorm1d(4); bn.running_mean.fill_(float(r))
+distrib.sync_buffers(bn)
+assert torch.allclose(bn.running_mean, torch.full((4,), 0.5))
+dist.barrier()
+print("WORKER_OK", r)
+'''
+
+
+def test_data_parallel_exchange_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(ROOT)], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"WORKER_OK {r}" in out, out
