@@ -16,8 +16,10 @@
 // (MT f32x16 accumulators, 1 B-operand + MT A-operand ds_read_b32 per MT MFMAs).  The input
 // window x[b][c0:c0+16][n0-halo : n0+128+halo] is staged ONCE in LDS and re-used by all KS taps
 // (the taps are just column offsets j*dil into the same LDS rows), weights arrive pre-packed as
-// [chunk][tap][16 channels][Mpad] so that the A tile is a straight, 16-byte-vectorised copy and
-// both MFMA operands are conflict-free consecutive-lane LDS reads.
+// [chunk][tap][16 channels][Mpad] so that the A slab of a (chunk, tap) stage is a straight,
+// 16-byte-vectorised copy and both MFMA operands are conflict-free consecutive-lane LDS reads.
+// The K loop is software-pipelined through registers with double-buffered LDS (one barrier per
+// stage): global loads of stage s+1 are issued before the 8*MT MFMAs of stage s.
 #include "bm_common.h"
 
 struct ConvNNArgs {
@@ -37,10 +39,14 @@ struct ConvNNArgs {
 };
 
 template <int MT>
-__global__ __launch_bounds__(256) void conv_nn_kernel(ConvNNArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
     constexpr int BM = 32 * MT;
     constexpr int BN = 128;
     constexpr int BKC = BM_BKC;
+    constexpr int Q = BM / 4;                         // float4 per A row
+    constexpr int AREG = (BKC * Q + 255) / 256;       // float4 per thread per (chunk, tap) A slab
+    constexpr int XROWS = BKC / 4;                    // X rows per wavefront
+    constexpr int XCOLS = 3;                          // 64-lane column passes: window <= 192 floats
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -61,14 +67,14 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(ConvNNArgs a) {
     const int m0 = mtile * BM;
     const int n0 = ntile * BN;
     const int halo = (a.KS >> 1) * a.dil;
-    const int XW = BN + 2 * halo;          // staged window width
-    const int KSB = a.KS * BKC;            // packed rows per chunk
-    float* As = smem;                      // [KSB][BM]
-    float* Xs = smem + KSB * BM;           // [BKC][XW]
+    const int XW = BN + 2 * halo;          // staged window width (<= 192)
+    // LDS: two A slabs [BKC][BM] (one per pipeline stage parity) + two X windows [BKC][XW]
+    float* As = smem;
+    float* Xs = smem + 2 * BKC * BM;
 
     const int g = a.widx ? a.widx[b] : 0;
     const float* xb = a.x + (long)b * a.x_bstride;
-    const float* wg = a.wp + (long)g * a.nchunk * KSB * a.Mpad + m0;
+    const float* wg = a.wp + (long)g * a.nchunk * a.KS * BKC * a.Mpad + m0;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -76,32 +82,78 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(ConvNNArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
+    // Software pipeline over stages s = chunk*KS + tap: while the MFMAs of stage s run from LDS,
+    // the A slab of stage s+1 (and, during the last tap of a chunk, the x window of chunk+1) is in
+    // flight from HBM/L2 into registers; it is written to the other LDS buffer after the MFMAs,
+    // one barrier per stage.
+    static_assert(AREG <= 3 && XROWS == 4 && XCOLS == 3, "staging register set");
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
+    float x00 = 0, x01 = 0, x02 = 0, x10 = 0, x11 = 0, x12 = 0, x20 = 0, x21 = 0, x22 = 0, x30 = 0,
+          x31 = 0, x32 = 0;
+    const int nstage = a.nchunk * a.KS;
+
+// NB: the staging registers are NAMED scalars handled by macros: arrays (even with fully unrolled
+// constant indices, or captured by lambdas) were left in scratch memory by hipcc's SROA.
+#define BM_A1(I_, V_)                                                                             \
+    if (I_ < AREG) {                                                                              \
+        int e = tid + I_ * 256;                                                                   \
+        e = e < BKC * Q ? e : BKC * Q - 1;          /* clamp: unconditional load, guarded store */ \
+        const int r = e / Q, q = e - r * Q;                                                       \
+        V_ = *reinterpret_cast<const float4*>(wsrc + (long)r * a.Mpad + q * 4);                   \
+    }
+#define BM_LOAD_A(S_)                                                                             \
+    {                                                                                             \
+        const float* wsrc = wg + (long)(S_) * BKC * a.Mpad;                                       \
+        BM_A1(0, a0) BM_A1(1, a1) BM_A1(2, a2)                                                    \
+    }
+#define BM_SA1(I_, V_)                                                                            \
+    if (I_ < AREG && tid + I_ * 256 < BKC * Q)                                                    \
+        *reinterpret_cast<float4*>(dst + (tid + I_ * 256) * 4) = V_;
+#define BM_STORE_A(BUF_)                                                                          \
+    {                                                                                             \
+        float* dst = As + (BUF_) * BKC * BM;                                                      \
+        BM_SA1(0, a0) BM_SA1(1, a1) BM_SA1(2, a2)                                                 \
+    }
+#define BM_X1(RR_, K_, V_)                                                                        \
+    {                                                                                             \
+        const int c = c0 + wave + RR_ * 4;                                                        \
+        const int xx = lane + K_ * 64;                                                            \
+        const int t = n0 - halo + xx;                                                             \
+        V_ = (xx < XW && c < a.Cin && t >= 0 && t < a.T) ? xb[(long)c * a.T + t] : 0.f;           \
+    }
+#define BM_LOAD_X(CHUNK_)                                                                         \
+    {                                                                                             \
+        const int c0 = (CHUNK_) * BKC;                                                            \
+        BM_X1(0, 0, x00) BM_X1(0, 1, x01) BM_X1(0, 2, x02) BM_X1(1, 0, x10) BM_X1(1, 1, x11)      \
+        BM_X1(1, 2, x12) BM_X1(2, 0, x20) BM_X1(2, 1, x21) BM_X1(2, 2, x22) BM_X1(3, 0, x30)      \
+        BM_X1(3, 1, x31) BM_X1(3, 2, x32)                                                         \
+    }
+#define BM_SX1(RR_, K_, V_)                                                                       \
+    if (lane + K_ * 64 < XW) dst[(wave + RR_ * 4) * XW + lane + K_ * 64] = V_;
+#define BM_STORE_X(BUF_)                                                                          \
+    {                                                                                             \
+        float* dst = Xs + (BUF_) * BKC * XW;                                                      \
+        BM_SX1(0, 0, x00) BM_SX1(0, 1, x01) BM_SX1(0, 2, x02) BM_SX1(1, 0, x10) BM_SX1(1, 1, x11) \
+        BM_SX1(1, 2, x12) BM_SX1(2, 0, x20) BM_SX1(2, 1, x21) BM_SX1(2, 2, x22) BM_SX1(3, 0, x30) \
+        BM_SX1(3, 1, x31) BM_SX1(3, 2, x32)                                                       \
+    }
+
+    BM_LOAD_A(0);
+    BM_LOAD_X(0);
+    BM_STORE_A(0);
+    BM_STORE_X(0);
+    __syncthreads();
+    int s = 0;
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        // ---- stage A: KSB rows of BM floats (float4 copies, rows are Mpad-strided) ----
-        const float* wsrc = wg + (long)chunk * KSB * a.Mpad;
-        constexpr int Q = BM / 4;
-        for (int e = tid; e < KSB * Q; e += 256) {
-            const int r = e / Q, q = e - r * Q;
-            const float4 v = *reinterpret_cast<const float4*>(wsrc + (long)r * a.Mpad + q * 4);
-            *reinterpret_cast<float4*>(As + r * BM + q * 4) = v;
-        }
-        // ---- stage X window: BKC rows of XW floats, zero outside [0,T) x [0,Cin) ----
-        const int c0 = chunk * BKC;
-        for (int cc = wave; cc < BKC; cc += 4) {
-            const int c = c0 + cc;
-            const float* xr = xb + (long)c * a.T;
-            for (int xx = lane; xx < XW; xx += 64) {
-                const int t = n0 - halo + xx;
-                float v = 0.f;
-                if (c < a.Cin && t >= 0 && t < a.T) v = xr[t];
-                Xs[cc * XW + xx] = v;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA: k runs over (tap j, channel pair p); lanes 0-31 feed k even, 32-63 k odd ----
-        for (int j = 0; j < a.KS; ++j) {
-            const float* xrow = Xs + h * XW + wave * 32 + nl + j * a.dil;
-            const float* arow = As + (j * BKC + h) * BM + nl;
+        const float* xbuf = Xs + (chunk & 1) * BKC * XW;
+        for (int j = 0; j < a.KS; ++j, ++s) {
+            const bool more_a = s + 1 < nstage;
+            const bool more_x = j == a.KS - 1 && chunk + 1 < a.nchunk;
+            if (more_a) BM_LOAD_A(s + 1);
+            if (more_x) BM_LOAD_X(chunk + 1);
+            // ---- MFMA: k runs over channel pairs; lanes 0-31 feed k even, 32-63 k odd ----
+            const float* xrow = xbuf + h * XW + wave * 32 + nl + j * a.dil;
+            const float* arow = As + (s & 1) * BKC * BM + h * BM + nl;
 #pragma unroll
             for (int p = 0; p < BKC / 2; ++p) {
                 const float bv = xrow[2 * p * XW];
@@ -111,9 +163,19 @@ __global__ __launch_bounds__(256) void conv_nn_kernel(ConvNNArgs a) {
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt], 0, 0, 0);
                 }
             }
+            if (more_a) BM_STORE_A((s + 1) & 1);
+            if (more_x) BM_STORE_X((chunk + 1) & 1);
+            __syncthreads();
         }
-        __syncthreads();
     }
+#undef BM_LOAD_A
+#undef BM_A1
+#undef BM_SA1
+#undef BM_X1
+#undef BM_SX1
+#undef BM_STORE_A
+#undef BM_LOAD_X
+#undef BM_STORE_X
 
     // ---- epilogue ----
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -177,10 +239,11 @@ static int launch_conv_nn(const ConvNNArgs& a, hipStream_t stream) {
     constexpr int BM = 32 * MT;
     const int halo = (a.KS >> 1) * a.dil;
     const int XW = 128 + 2 * halo;
-    size_t lds = (size_t)(a.KS * BM_BKC * BM + BM_BKC * XW) * sizeof(float);
+    if (XW > 192)
+        return bm_set_error(BM_ERR_UNSUPPORTED, "conv_nn: (kernel_size/2)*dilation = %d exceeds the 32-sample halo of the staged window", halo);
+    size_t lds = (size_t)(2 * BM_BKC * BM + 2 * BM_BKC * XW) * sizeof(float);
     const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
-    if (lds > 160 * 1024) return bm_set_error(BM_ERR_UNSUPPORTED, "conv_nn: LDS tile %zu B too large (KS=%d dil=%d)", lds, a.KS, a.dil);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_kernel<MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

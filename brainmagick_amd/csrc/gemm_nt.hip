@@ -29,13 +29,23 @@ struct GemmNTArgs {
     int tiles_m, tiles_c;
 };
 
-template <int WM, int WC, int MT, int NT, int KS>
+template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
+
+// XWP = padded width of the staged X window (32 + 2*halo <= XWP), compile time so that the staging
+// registers can be a fixed-size vector.
+template <int WM, int WC, int MT, int NT, int KS, int XWP>
 __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
     constexpr int NW = WM * WC;
     constexpr int NTH = NW * 64;
     constexpr int BM = WM * MT * 32;
     constexpr int BC = WC * NT * 32;
     constexpr int PA = BKT + 1;
+    constexpr int PX = XWP + 1;                     // odd pitch -> conflict-free row-per-lane reads
+    constexpr int AVN = BM * BKT / NTH;             // staged A floats per thread
+    constexpr int XVN = (BC * XWP + NTH - 1) / NTH; // staged X floats per thread
+    static_assert(BM * BKT % NTH == 0, "A tile must split evenly");
+    typedef typename FVec<AVN>::type avec_t;
+    typedef typename FVec<XVN>::type xvec_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -45,13 +55,12 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
     const int nl = lane & 31, h = lane >> 5;
 
     const int halo = (KS >> 1) * a.dil;
-    const int XW = BKT + 2 * halo;
-    const int PX = XW | 1;                     // odd pitch
     float* As = smem;                          // [BM][PA]
     float* Xs = smem + BM * PA;                // [BC][PX]
 
-    // block -> (tile_m, tile_c, split, g)
-    int id = blockIdx.x;
+    // block -> (tile_m, tile_c, split, g).  XCD-aware: all tiles of one (g, split) -- which stream
+    // the SAME segments -- get consecutive logical ids, i.e. run on one XCD and share its L2.
+    int id = bm_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id % a.tiles_m; id /= a.tiles_m;
     const int tc = id % a.tiles_c; id /= a.tiles_c;
     const int split = id % a.nsplit;
@@ -75,34 +84,52 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][k][j][r] = 0.f;
 
+    avec_t areg;
+    xvec_t xreg;
+    int t0 = 0;
+
+    // Issue the global loads of chunk q into registers (no wait).
+#define NT_LOAD(Q_)                                                                               \
+    {                                                                                             \
+        const int sl = (int)((Q_) / cps);                                                         \
+        t0 = (int)((Q_) - (long)sl * cps) * BKT;                                                  \
+        int sidx = s_begin + sl;                                                                  \
+        if (a.order) sidx = a.order[sidx];                                                        \
+        const float* ab = a.a + (long)sidx * a.a_sstride;                                         \
+        const float* xb = a.x + (long)sidx * a.x_sstride;                                         \
+        _Pragma("unroll") for (int k = 0; k < AVN; ++k) {                                         \
+            const int i = (tid >> 5) + k * (NTH / 32);                                            \
+            const int m = m0 + i, t = t0 + (tid & 31);                                            \
+            areg[k] = (m < a.M && t < a.T) ? ab[(long)m * a.a_rstride + t] : 0.f;                 \
+        }                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < XVN; ++k) {                                         \
+            const int e = tid + k * NTH;                                                          \
+            const int i = e / XWP, xx = e - i * XWP;                                              \
+            const int c = c0 + i, t = t0 - halo + xx;                                             \
+            xreg[k] = (i < BC && c < a.Cn && t >= 0 && t < a.T) ? xb[(long)c * a.x_rstride + t] : 0.f; \
+        }                                                                                         \
+    }
+#define NT_STORE()                                                                                \
+    {                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < AVN; ++k)                                           \
+            As[((tid >> 5) + k * (NTH / 32)) * PA + (tid & 31)] = areg[k];                        \
+        _Pragma("unroll") for (int k = 0; k < XVN; ++k) {                                         \
+            const int e = tid + k * NTH;                                                          \
+            const int i = e / XWP, xx = e - i * XWP;                                              \
+            if (i < BC) Xs[i * PX + xx] = xreg[k];                                                \
+        }                                                                                         \
+    }
+
+    if (q_begin < q_end) {
+        NT_LOAD(q_begin);
+        NT_STORE();
+    }
+    __syncthreads();
     for (long q = q_begin; q < q_end; ++q) {
-        const int sl = (int)(q / cps);
-        const int t0 = (int)(q - (long)sl * cps) * BKT;
-        int s = s_begin + sl;
-        if (a.order) s = a.order[s];
-        const float* ab = a.a + (long)s * a.a_sstride;
-        const float* xb = a.x + (long)s * a.x_sstride;
-        // stage A rows: half-wave per row, 32 consecutive floats
-        for (int i = tid >> 5; i < BM; i += NTH / 32) {
-            const int m = m0 + i, t = t0 + (tid & 31);
-            float v = 0.f;
-            if (m < a.M && t < a.T) v = ab[(long)m * a.a_rstride + t];
-            As[i * PA + (tid & 31)] = v;
-        }
-        // stage X rows with halo
-        for (int i = wave; i < BC; i += NW) {
-            const int c = c0 + i;
-            const float* xr = xb + (long)c * a.x_rstride;
-            for (int xx = lane; xx < XW; xx += 64) {
-                const int t = t0 - halo + xx;
-                float v = 0.f;
-                if (c < a.Cn && t >= 0 && t < a.T) v = xr[t];
-                Xs[i * PX + xx] = v;
-            }
-        }
-        __syncthreads();
         const int tvalid = min(BKT, a.T - t0);
         const int ksteps = (tvalid + 1) >> 1;
+        const bool more = q + 1 < q_end;
+        if (more) NT_LOAD(q + 1);              // in flight during the MFMAs below (t0 now = next chunk)
         const float* ap = As + (wm * MT * 32 + nl) * PA + h;
         const float* xp = Xs + (wc * NT * 32 + nl) * PX + h;
         for (int kk = 0; kk < ksteps; ++kk) {
@@ -121,7 +148,13 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
             }
         }
         __syncthreads();
+        if (more) {
+            NT_STORE();
+            __syncthreads();
+        }
     }
+#undef NT_LOAD
+#undef NT_STORE
 
     // epilogue: part[(g*nsplit+split)][m][c*KS + j]
     const long N = (long)a.Cn * KS;
@@ -142,15 +175,12 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
         }
 }
 
-template <int WM, int WC, int MT, int NT, int KS>
-static int launch_gemm_nt(GemmNTArgs a, hipStream_t stream) {
+template <int WM, int WC, int MT, int NT, int KS, int XWP>
+static int launch_gemm_nt_w(GemmNTArgs a, hipStream_t stream) {
     constexpr int BM = WM * MT * 32, BC = WC * NT * 32;
-    const int halo = (KS >> 1) * a.dil;
-    const int PX = (BKT + 2 * halo) | 1;
-    const size_t lds = (size_t)(BM * (BKT + 1) + BC * PX) * sizeof(float);
-    if (lds > 160 * 1024) return bm_set_error(BM_ERR_UNSUPPORTED, "gemm_nt: LDS tile too large (dil=%d)", a.dil);
+    const size_t lds = (size_t)(BM * (BKT + 1) + BC * (XWP + 1)) * sizeof(float);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<WM, WC, MT, NT, KS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<WM, WC, MT, NT, KS, XWP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
@@ -158,9 +188,18 @@ static int launch_gemm_nt(GemmNTArgs a, hipStream_t stream) {
     a.tiles_c = cdiv(a.Cn, BC);
     const long nblocks = (long)a.tiles_m * a.tiles_c * a.nsplit * a.G;
     if (nblocks <= 0) return BM_OK;
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WC, MT, NT, KS>), dim3((unsigned)nblocks), dim3(WM * WC * 64),
-                       lds, stream, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WC, MT, NT, KS, XWP>), dim3((unsigned)nblocks),
+                       dim3(WM * WC * 64), lds, stream, a);
     return bm_check_launch("gemm_nt");
+}
+
+template <int WM, int WC, int MT, int NT, int KS>
+static int launch_gemm_nt(GemmNTArgs a, hipStream_t stream) {
+    const int halo = (KS >> 1) * a.dil;
+    if (KS == 1) return launch_gemm_nt_w<WM, WC, MT, NT, KS, 32>(a, stream);
+    if (halo <= 16) return launch_gemm_nt_w<WM, WC, MT, NT, KS, 64>(a, stream);
+    if (halo <= 32) return launch_gemm_nt_w<WM, WC, MT, NT, KS, 96>(a, stream);
+    return bm_set_error(BM_ERR_UNSUPPORTED, "gemm_nt: (kernel_size/2)*dilation = %d exceeds the 32-sample halo", halo);
 }
 
 // Picks the tile (128 or 64 rows / cols) with the least padding.
