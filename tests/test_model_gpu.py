@@ -37,7 +37,7 @@ def is_noise_grad(g, ref_scale):
     return g.abs().max().item() <= 10 * NOISE * ref_scale
 
 
-def adam_params_close(p, p_ref, nsteps, lr=3e-4):
+def adam_params_close(p, p_ref, nsteps, g_ref=None, gscale=1.0, lr=3e-4):
     """After-step parameter check that is robust to Adam's sign amplification: at step 1 the update
     is lr * g / (|g| + eps) = +-lr whatever |g|, so an element whose gradient is round-off noise
     around 0 may legitimately move by +lr in one implementation and -lr in the other (sensor-attention
@@ -47,8 +47,23 @@ def adam_params_close(p, p_ref, nsteps, lr=3e-4):
     (step k+1's loss sees step k's update), the step-0 gradients and test_adam_kernel (bitwise-close
     Adam arithmetic given identical gradients)."""
     d = (p.detach().double().cpu() - p_ref.detach().double().cpu()).abs()
-    frac_bad = (d > 1e-6).double().mean().item()
+    bad = d > 1e-6
+    if g_ref is not None:
+        # elements whose reference gradient is itself round-off noise (e.g. the k=0 cosine column of
+        # the attention heads: sum_c dsoftmax == 0) are not counted
+        bad &= g_ref.detach().double().cpu().abs() > 10 * NOISE * gscale
+    frac_bad = bad.double().mean().item()
     return frac_bad <= 1e-2 and d.max().item() <= 2.1 * lr * nsteps, (frac_bad, d.max().item())
+
+
+def running_stat_close(v, v_ref, nsteps, lr=3e-4, momentum=0.1):
+    """BatchNorm running statistics: tight (2e-5 rel-L2) after one step; from the second step on the
+    batch mean absorbs the noise-driven +-lr drift of the conv bias in front of the BatchNorm (see
+    is_noise_grad), i.e. up to momentum * 2*lr per extra step in absolute terms."""
+    if rel_l2(v, v_ref) < 2e-5:
+        return True
+    d = (v.detach().double().cpu() - v_ref.detach().double().cpu()).abs().max().item()
+    return d <= 2.1 * lr * momentum * (nsteps - 1) + 1e-6
 
 
 class _Batch:
@@ -123,10 +138,10 @@ def test_against_reference_golden(name):
             if not v.is_floating_point():
                 assert int(v) == int(sd1[k]), k
             elif k in grads_ref:
-                ok, info = adam_params_close(v, sd1[k], meta["n_steps"])
+                ok, info = adam_params_close(v, sd1[k], meta["n_steps"], grads_ref[k], gscale)
                 assert ok, (k, info)
             else:
-                assert rel_l2(v, sd1[k]) < 2e-5, k      # BatchNorm running statistics
+                assert running_stat_close(v, sd1[k], meta["n_steps"]), k
     else:
         model.eval()
         loss_mod.eval()
@@ -201,10 +216,10 @@ def test_paper_model_step_against_oracle(cfg_name, B, T):
         if not v.is_floating_point():
             continue
         if k in grads_ref:
-            ok, info = adam_params_close(v, oracle.sd[k], 2)
+            ok, info = adam_params_close(v, oracle.sd[k], 2, grads_ref[k], gscale)
             assert ok, (k, info)
         else:
-            assert rel_l2(v, oracle.sd[k]) < 2e-5, k
+            assert running_stat_close(v, oracle.sd[k], 2), k
 
 
 def test_full_batch_properties():
