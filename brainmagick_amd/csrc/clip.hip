@@ -101,3 +101,59 @@ extern "C" int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, 
     if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, loss_row, B, loss);
     return bm_check_launch("clip_ce");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Retrieval evaluation (scripts/run_eval_probs.py:237-264 _get_accuracy_from_probs; bm/wer.py:104-111):
+// top-k columns of every probability / score row and "is the row's label among the labels of its
+// top-k candidates".  One wavefront per row; k selection passes, each a strided scan + wave arg-max
+// (ties broken towards the lower column index), no per-lane candidate lists (k stays in SGPR-land).
+// ------------------------------------------------------------------------------------------------
+__global__ void topk_rows_kernel(const float* __restrict__ x, int rows, int cols, int k,
+                                 int* __restrict__ idx_out, float* __restrict__ val_out,
+                                 const long* __restrict__ col_labels, const long* __restrict__ row_labels,
+                                 int* __restrict__ hit_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * cols;
+    float prev_v = INFINITY;
+    int prev_i = -1;
+    int hit = 0;
+    const long want = row_labels ? row_labels[row] : 0;
+    for (int p = 0; p < k; ++p) {
+        float best_v = -INFINITY;
+        int best_i = cols;               // sentinel: nothing left
+        for (int c = lane; c < cols; c += 64) {
+            const float v = xr[c];
+            const bool eligible = (v < prev_v) || (v == prev_v && c > prev_i);
+            if (eligible && (v > best_v || (v == best_v && c < best_i))) { best_v = v; best_i = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best_v, o);
+            const int oi = __shfl_xor(best_i, o);
+            if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+        }
+        if (best_i >= cols) best_i = -1;  // fewer than k columns
+        if (lane == 0) {
+            if (idx_out) idx_out[(long)row * k + p] = best_i;
+            if (val_out) val_out[(long)row * k + p] = best_v;
+        }
+        if (best_i >= 0 && col_labels && col_labels[best_i] == want) hit = 1;
+        prev_v = best_v;
+        prev_i = best_i < 0 ? cols : best_i;
+    }
+    if (lane == 0 && hit_out) hit_out[row] = hit;
+}
+
+extern "C" int bm_topk_rows(const float* x, int rows, int cols, int k, int* idx_out, float* val_out,
+                            const long* col_labels, const long* row_labels, int* hit_out, void* stream) {
+    BM_REQUIRE(x, "topk_rows: null pointer");
+    BM_REQUIRE(k >= 1 && cols >= 1, "topk_rows: bad k/cols");
+    BM_REQUIRE((col_labels == nullptr) == (row_labels == nullptr), "topk_rows: labels come in pairs");
+    BM_REQUIRE(!hit_out || col_labels, "topk_rows: hit_out needs labels");
+    if (rows == 0) return BM_OK;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       cols, k, idx_out, val_out, col_labels, row_labels, hit_out);
+    return bm_check_launch("topk_rows");
+}

@@ -132,21 +132,29 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
         if (more) NT_LOAD(q + 1);              // in flight during the MFMAs below (t0 now = next chunk)
         const float* ap = As + (wm * MT * 32 + nl) * PA + h;
         const float* xp = Xs + (wc * NT * 32 + nl) * PX + h;
-        for (int kk = 0; kk < ksteps; ++kk) {
-            float av[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = ap[i * 32 * PA + 2 * kk];
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const float bv = xp[k * 32 * PX + 2 * kk + j * a.dil];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        acc[i][k][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][k][j], 0, 0, 0);
-                }
-            }
+#define NT_KSTEP(KK_)                                                                              \
+    {                                                                                             \
+        float av[MT];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) av[i] = ap[i * 32 * PA + 2 * (KK_)];       \
+        _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                          \
+            _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                      \
+                const float bv = xp[k * 32 * PX + 2 * (KK_) + j * a.dil];                         \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][k][j] =                     \
+                    __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][k][j], 0, 0, 0);       \
+            }                                                                                     \
+        }                                                                                         \
+    }
+        // groups of 4 k-steps, fully unrolled inside: hipcc hoists the 4*(MT + NT*KS) LDS operand
+        // reads of a group over its MFMAs; a partial last chunk only runs the groups it needs
+        // (the LDS tile is zero-filled beyond T).
+        const int kgroups = (ksteps + 3) >> 2;
+        for (int g4 = 0; g4 < kgroups; ++g4) {
+            NT_KSTEP(4 * g4 + 0)
+            NT_KSTEP(4 * g4 + 1)
+            NT_KSTEP(4 * g4 + 2)
+            NT_KSTEP(4 * g4 + 3)
         }
+#undef NT_KSTEP
         __syncthreads();
         if (more) {
             NT_STORE();

@@ -23,8 +23,14 @@ import torch
 import torch.distributed as dist
 
 
+def _forced() -> bool:
+    # BM_FORCE_DISTRIBUTED=1 runs the collective code path even at world_size 1 (used by the GPU
+    # test that exercises the real RCCL calls on the single-GPU test box).
+    return os.environ.get("BM_FORCE_DISTRIBUTED", "0") == "1"
+
+
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
 
 
 def rank() -> int:
@@ -37,7 +43,7 @@ def world_size() -> int:
 
 def init(backend: tp.Optional[str] = None):
     """flashy.distrib.init (bm/train.py:139): rendezvous from the torchrun environment."""
-    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if "RANK" not in os.environ or (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not _forced()):
         return
     if dist.is_initialized():
         return

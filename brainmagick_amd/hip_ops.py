@@ -353,6 +353,20 @@ def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
     return scores, probs, dscaled, loss
 
 
+def topk_rows(x: torch.Tensor, k: int, col_labels=None, row_labels=None):
+    """x [N, V] -> (idx [N, k] int32, values [N, k], hits [N] int32 | None)."""
+    _req(x, "topk_rows.x")
+    N, V = x.shape
+    idx = torch.empty(N, k, device=x.device, dtype=torch.int32)
+    val = torch.empty(N, k, device=x.device, dtype=torch.float32)
+    hits = torch.empty(N, device=x.device, dtype=torch.int32) if col_labels is not None else None
+    check(lib().bm_topk_rows(_p(x), N, V, k, _p(idx), _p(val),
+                             _p(_opt(col_labels, "col_labels", torch.int64)),
+                             _p(_opt(row_labels, "row_labels", torch.int64)), _p(hits), _stream()),
+          "bm_topk_rows")
+    return idx, val, hits
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float, beta2: float,
               eps: float, grad_scale: float = 1.0):
     for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):

@@ -103,6 +103,11 @@ int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scor
                float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
                void* stream);
 
+/* Retrieval evaluation: top-k columns per row + "own label among the top-k labels" hit flag.
+ * Replaces probs.topk + label gather/compare of scripts/run_eval_probs.py:237-264 and bm/wer.py:104-111. */
+int bm_topk_rows(const float* x, int rows, int cols, int k, int* idx_out, float* val_out,
+                 const long* col_labels, const long* row_labels, int* hit_out, void* stream);
+
 /* ---- fused Adam on the flat bucket (adam.hip)  torch.optim.Adam @ bm/train.py:118-119 ---- */
 int bm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
                  double lr, double beta1, double beta2, double eps, double grad_scale, void* stream);

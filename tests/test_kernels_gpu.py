@@ -284,3 +284,33 @@ def test_cpu_tensors_are_rejected(H):
     from brainmagick_amd._lib import BmHipError
     with pytest.raises(BmHipError):
         H.glu_fwd(torch.randn(2, 4, 8))
+
+
+def test_topk_rows_and_retrieval_accuracy(H):
+    """bm_topk_rows vs torch.topk + the reference rule of scripts/run_eval_probs.py:237-264."""
+    from brainmagick_amd import retrieval
+    from brainmagick_amd.losses import ClipLoss
+    g = _gen(21)
+    probs = torch.softmax(torch.randn(37, 301, generator=g) * 3, 1)
+    labels = torch.randint(0, 40, (301,), generator=g)
+    rows = labels[:37].clone()
+    idx, val, hits = H.topk_rows(probs.cuda(), 10, labels.cuda(), rows.cuda())
+    ref = probs.topk(10, dim=1)
+    assert torch.equal(idx.cpu().long(), ref.indices)
+    assert torch.equal(val.cpu(), ref.values)
+    for k in (1, 5, 10):
+        assert retrieval.get_accuracy_from_probs(probs.cuda(), rows, labels, k) == \
+            pytest.approx(O.topk_accuracy(probs, labels, rows, k))
+    # fewer columns than k, ties
+    small = torch.tensor([[0.5, 0.5, 0.0], [0.1, 0.2, 0.7]])
+    idx, _, _ = H.topk_rows(small.cuda(), 5)
+    assert idx.cpu().tolist() == [[0, 1, 2, -1, -1], [2, 1, 0, -1, -1]]
+    # end to end: probabilities of every candidate, batched, vs the oracle
+    est = torch.randn(50, 6, 40, generator=g)
+    cand = torch.randn(70, 6, 40, generator=g)
+    cand[:50] += 0.5 * est
+    pr = retrieval.builds_probs(ClipLoss().cuda(), est, cand, batch_size=16)
+    assert rel_l2(pr, O.clip_probabilities(est.double(), cand.double())) < 1e-5
+    acc = retrieval.segment_topk_accuracy(ClipLoss().cuda(), est, cand, batch_size=16)
+    ref_acc = O.topk_accuracy(O.clip_probabilities(est, cand), torch.arange(70), torch.arange(50), 10)
+    assert acc["top10"] == pytest.approx(ref_acc)

@@ -274,3 +274,93 @@ def test_eval_mode_single_kernel_layers_match_train_stats_path():
                               act=H.ACT_GELU, want_pre=True)
     two_pass = H.affine_act_res(pre, scale, shift, x, H.ACT_GELU)
     assert torch.equal(fused, two_pass)
+
+
+NCCL_WORKER = r'''
+import os, sys, copy, torch
+sys.path.insert(0, sys.argv[1])
+from brainmagick_amd import distrib, synthetic
+from brainmagick_amd.models import SimpleConv
+from brainmagick_amd.solver import Solver
+cfg = dict(depth=4, kernel_size=3, dilation_period=5, batch_norm=True, skip=True, gelu=True, glu=2,
+           glu_context=1, complex_out=True, merger=True, merger_pos_dim=128, merger_channels=24,
+           merger_dropout=0.0, initial_linear=24, subject_layers=True, subject_dim=0)
+def run(negatives):
+    torch.manual_seed(0)
+    model = SimpleConv(in_channels={"meg": 30}, out_channels=12, hidden={"meg": 32}, n_subjects=4, **cfg)
+    solver = Solver(model, negatives=negatives)
+    sb = synthetic.make_batch(8, 30, 64, 12, 4, seed=3)
+    losses = [float(solver.train_step(sb)) for _ in range(3)]
+    return losses, solver.optimizer.flat_param.clone()
+plain_losses, plain_params = run("local")          # before init: world_size 1, no collectives
+os.environ["BM_FORCE_DISTRIBUTED"] = "1"
+distrib.init("nccl")
+assert distrib.is_distributed() and distrib.world_size() == 1
+rccl_losses, rccl_params = run("node")             # reduce_scatter / all_gather / candidate gather on RCCL
+assert plain_losses == rccl_losses, (plain_losses, rccl_losses)
+assert torch.equal(plain_params, rccl_params)
+m = distrib.average_metrics({"loss": 2.0}, 3)
+assert abs(m["loss"] - 2.0) < 1e-6
+distrib.sync_buffers(torch.nn.BatchNorm1d(4).cuda())
+torch.distributed.destroy_process_group()
+print("NCCL_WORKER_OK")
+'''
+
+
+def test_rccl_code_path_world1(tmp_path):
+    """The real RCCL collectives (reduce_scatter_tensor / all_gather_into_tensor on the flat bucket,
+    candidate all-gather on the side stream) at world_size 1 must reproduce the plain step bit for
+    bit.  (Multi-rank semantics are covered by the 2-process gloo test on CPU.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BM_FORCE_DISTRIBUTED", None)
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(script), str(root)], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "NCCL_WORKER_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_training_curve_and_top10_parity():
+    """SURVEY.md §8d accuracy parity, scaled to what the CPU oracle does in seconds: train the same
+    initial state on the same learnable (planted-latent) batches with the HIP path and with the
+    oracle; the loss curves must agree within 1 % (relative, every step) and the top-10 / top-1
+    segment-retrieval accuracy on 256 held-out segments within +-1 point of each other."""
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.losses import ClipLoss
+    from brainmagick_amd import retrieval
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=32, initial_linear=32, depth=6,
+               merger_dropout=0.0)
+    C, T, Fd, S, B, hidden, steps = 24, 96, 16, 4, 32, 48, 60
+    torch.manual_seed(5)
+    model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden},
+                       n_subjects=S, **cfg)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, hidden, Fd)
+    solver = Solver(model)
+    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True) for i in range(8)]
+    hip_losses, ref_losses = [], []
+    for step in range(steps):
+        sb = batches[step % len(batches)]
+        hip_losses.append(float(solver.train_step(sb)))
+        ref_losses.append(float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index,
+                                                  sb.features)[0]))
+    hip, ref = torch.tensor(hip_losses), torch.tensor(ref_losses)
+    assert ref[-8:].mean() < 0.8 * ref[:8].mean(), "planted task should be learnable"
+    assert ((hip - ref).abs() / ref.abs()).max().item() < 1e-2, (hip_losses[-5:], ref_losses[-5:])
+    held = synthetic.make_batch(256, C, T, Fd, S, seed=999, planted=True)
+    est_hip, cand = solver.predict(held)
+    est_ref = oracle.forward(held.meg, held.positions(), held.subject_index)
+    acc_hip = retrieval.segment_topk_accuracy(ClipLoss().cuda(), est_hip, cand, topks=(1, 10))
+    probs_ref = O.clip_probabilities(est_ref, held.features)
+    labels = torch.arange(256)
+    for k in (1, 10):
+        acc_ref = O.topk_accuracy(probs_ref, labels, labels, k)
+        assert abs(acc_hip[f"top{k}"] - acc_ref) <= 0.01 + 1e-9, (k, acc_hip, acc_ref)
+    assert acc_hip["top10"] > 5 * 10 / 256, "must beat chance (10/256) by a wide margin"
