@@ -59,6 +59,21 @@ def algorithmic_flops_per_segment(C, T, F, hidden=320, merger_ch=270) -> float:
     return 2.0 * 3.0 * mac
 
 
+def pmc_traffic(kernel_label: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected per MI355X_MICROARCH.md;
+    see profiles/*pmc_summary.json).  PMC counters cannot be sampled from inside this process."""
+    files = sorted((ROOT / "profiles").glob("*pmc_summary*.json"))
+    if not files:
+        return None, None
+    data = json.loads(files[-1].read_text())
+    prefix = kernel_label.rstrip(">")
+    for name, rec in data.get("kernels", {}).items():
+        if name.startswith(prefix):
+            return rec.get("hbm_bytes_per_launch_corrected"), files[-1].name
+    return None, files[-1].name
+
+
 def cpu_baseline(workload, seconds_budget=20.0):
     """The CPU oracle (port of the reference path) timed on the host cores, bounded sample."""
     from oracle import bm_oracle as O
@@ -142,6 +157,7 @@ def main():
     d = ksum[dom]
     achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
     seg_flops = algorithmic_flops_per_segment(c["C"], c["T"], c["F"])
+    traffic, traffic_src = pmc_traffic(dom)
     total_kernel_ms = sum(v["avg_ms"] * v["launches"] for v in ksum.values()) / args.steps
     out = {
         "metric": "segments/s, 208-ch x 360-sample SimpleConv + ClipLoss training step",
@@ -159,7 +175,9 @@ def main():
                    "step_tflops": seg_flops * B * world * args.steps / elapsed / 1e12},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
+                     "traffic_source": traffic_src,
                      "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,
                      "algorithmic_flops_per_launch": d["flops_per_launch"],
                      "mfma_kernels_ms_per_step": total_kernel_ms,

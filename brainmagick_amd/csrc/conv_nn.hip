@@ -38,7 +38,7 @@ struct ConvNNArgs {
     int ntiles_n, ntiles_m;
 };
 
-template <int MT>
+template <int MT, bool VEC>
 __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
     constexpr int BM = 32 * MT;
     constexpr int BN = 128;
@@ -67,7 +67,12 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
     const int m0 = mtile * BM;
     const int n0 = ntile * BN;
     const int halo = (a.KS >> 1) * a.dil;
-    const int XW = BN + 2 * halo;          // staged window width (<= 192)
+    // staged x window: [n0 - HP, n0 + BN + HP).  VEC (T % 4 == 0, 16-byte aligned rows): HP = halo
+    // rounded up to a multiple of 4 so that every global access is a dwordx4 lying entirely inside
+    // or outside [0, T); otherwise HP = halo and the window is filled with dword loads.
+    const int HP = VEC ? ((halo + 3) & ~3) : halo;
+    const int XW = BN + 2 * HP;            // staged window width (<= 192)
+    const int xoff = HP - halo;            // column of tap 0, output column 0 inside the window
     // LDS: two A slabs [BKC][BM] (one per pipeline stage parity) + two X windows [BKC][XW]
     float* As = smem;
     float* Xs = smem + 2 * BKC * BM;
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
     float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
     float x00 = 0, x01 = 0, x02 = 0, x10 = 0, x11 = 0, x12 = 0, x20 = 0, x21 = 0, x22 = 0, x30 = 0,
           x31 = 0, x32 = 0;
+    float4 xv0 = a0, xv1 = a0, xv2 = a0, xv3 = a0;
     const int nstage = a.nchunk * a.KS;
 
 // NB: the staging registers are NAMED scalars handled by macros: arrays (even with fully unrolled
@@ -118,24 +124,45 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
     {                                                                                             \
         const int c = c0 + wave + RR_ * 4;                                                        \
         const int xx = lane + K_ * 64;                                                            \
-        const int t = n0 - halo + xx;                                                             \
+        const int t = n0 - HP + xx;                                                               \
         V_ = (xx < XW && c < a.Cin && t >= 0 && t < a.T) ? xb[(long)c * a.T + t] : 0.f;           \
+    }
+#define BM_XV1(RR_, V_)                                                                           \
+    {                                                                                             \
+        const int c = c0 + wave + RR_ * 4;                                                        \
+        const int t = n0 - HP + 4 * lane;                                                         \
+        V_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+        if (4 * lane < XW && c < a.Cin && t >= 0 && t < a.T)                                      \
+            V_ = *reinterpret_cast<const float4*>(xb + (long)c * a.T + t);                        \
     }
 #define BM_LOAD_X(CHUNK_)                                                                         \
     {                                                                                             \
         const int c0 = (CHUNK_) * BKC;                                                            \
+        if constexpr (VEC) {                                                                      \
+            BM_XV1(0, xv0) BM_XV1(1, xv1) BM_XV1(2, xv2) BM_XV1(3, xv3)                           \
+        } else {                                                                                  \
         BM_X1(0, 0, x00) BM_X1(0, 1, x01) BM_X1(0, 2, x02) BM_X1(1, 0, x10) BM_X1(1, 1, x11)      \
         BM_X1(1, 2, x12) BM_X1(2, 0, x20) BM_X1(2, 1, x21) BM_X1(2, 2, x22) BM_X1(3, 0, x30)      \
         BM_X1(3, 1, x31) BM_X1(3, 2, x32)                                                         \
+        }                                                                                         \
     }
 #define BM_SX1(RR_, K_, V_)                                                                       \
     if (lane + K_ * 64 < XW) dst[(wave + RR_ * 4) * XW + lane + K_ * 64] = V_;
 #define BM_STORE_X(BUF_)                                                                          \
     {                                                                                             \
         float* dst = Xs + (BUF_) * BKC * XW;                                                      \
+        if constexpr (VEC) {                                                                      \
+            if (4 * lane < XW) {                                                                  \
+                *reinterpret_cast<float4*>(dst + (wave + 0) * XW + 4 * lane) = xv0;               \
+                *reinterpret_cast<float4*>(dst + (wave + 4) * XW + 4 * lane) = xv1;               \
+                *reinterpret_cast<float4*>(dst + (wave + 8) * XW + 4 * lane) = xv2;               \
+                *reinterpret_cast<float4*>(dst + (wave + 12) * XW + 4 * lane) = xv3;              \
+            }                                                                                     \
+        } else {                                                                                  \
         BM_SX1(0, 0, x00) BM_SX1(0, 1, x01) BM_SX1(0, 2, x02) BM_SX1(1, 0, x10) BM_SX1(1, 1, x11) \
         BM_SX1(1, 2, x12) BM_SX1(2, 0, x20) BM_SX1(2, 1, x21) BM_SX1(2, 2, x22) BM_SX1(3, 0, x30) \
         BM_SX1(3, 1, x31) BM_SX1(3, 2, x32)                                                       \
+        }                                                                                         \
     }
 
     BM_LOAD_A(0);
@@ -152,7 +179,7 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
             if (more_a) BM_LOAD_A(s + 1);
             if (more_x) BM_LOAD_X(chunk + 1);
             // ---- MFMA: k runs over channel pairs; lanes 0-31 feed k even, 32-63 k odd ----
-            const float* xrow = xbuf + h * XW + wave * 32 + nl + j * a.dil;
+            const float* xrow = xbuf + h * XW + wave * 32 + nl + xoff + j * a.dil;
             const float* arow = As + (s & 1) * BKC * BM + h * BM + nl;
 #pragma unroll
             for (int p = 0; p < BKC / 2; ++p) {
@@ -172,6 +199,7 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
 #undef BM_A1
 #undef BM_SA1
 #undef BM_X1
+#undef BM_XV1
 #undef BM_SX1
 #undef BM_STORE_A
 #undef BM_LOAD_X
@@ -234,25 +262,36 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
     }
 }
 
-template <int MT>
-static int launch_conv_nn(const ConvNNArgs& a, hipStream_t stream) {
+template <int MT, bool VEC>
+static int launch_conv_nn_v(const ConvNNArgs& a, hipStream_t stream) {
     constexpr int BM = 32 * MT;
     const int halo = (a.KS >> 1) * a.dil;
-    const int XW = 128 + 2 * halo;
+    const int HP = VEC ? ((halo + 3) & ~3) : halo;
+    const int XW = 128 + 2 * HP;
     if (XW > 192)
         return bm_set_error(BM_ERR_UNSUPPORTED, "conv_nn: (kernel_size/2)*dilation = %d exceeds the 32-sample halo of the staged window", halo);
     size_t lds = (size_t)(2 * BM_BKC * BM + 2 * BM_BKC * XW) * sizeof(float);
     const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_kernel<MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_kernel<MT, VEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "conv_nn: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const long nblocks = (long)a.B * a.ntiles_n * a.ntiles_m;
     if (nblocks <= 0) return BM_OK;
-    hipLaunchKernelGGL(conv_nn_kernel<MT>, dim3((unsigned)nblocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_nn_kernel<MT, VEC>), dim3((unsigned)nblocks), dim3(256), lds, stream, a);
     return bm_check_launch("conv_nn");
+}
+
+template <int MT>
+static int launch_conv_nn(const ConvNNArgs& a, hipStream_t stream) {
+    // the 5-block tile is register-bound at 3 waves/SIMD: its x window stays on the 12-dword staging
+    // set (the 4 x dwordx4 set spills); smaller tiles take the vector path.
+    const bool vec = MT < 5 && (a.T % 4 == 0) && (a.x_bstride % 4 == 0) && ((uintptr_t)a.x % 16 == 0);
+    if constexpr (MT < 5)
+        if (vec) return launch_conv_nn_v<MT, true>(a, stream);
+    return launch_conv_nn_v<MT, false>(a, stream);
 }
 
 // Row-tile height (in 32-row MFMA blocks) that minimises padded rows for M output channels.

@@ -32,8 +32,10 @@ struct GemmNTArgs {
 template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
 
 // XWP = padded width of the staged X window (32 + 2*halo <= XWP), compile time so that the staging
-// registers can be a fixed-size vector.
-template <int WM, int WC, int MT, int NT, int KS, int XWP>
+// registers can be a fixed-size vector.  The window is centred: it starts HP = (XWP-32)/2 samples
+// before the chunk, a multiple of 4, so that with VEC (T % 4 == 0, 16-byte aligned rows) every
+// global access is a dwordx4 that lies entirely inside or outside [0, T).
+template <int WM, int WC, int MT, int NT, int KS, int XWP, bool VEC>
 __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
     constexpr int NW = WM * WC;
     constexpr int NTH = NW * 64;
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
     constexpr int AVN = BM * BKT / NTH;             // staged A floats per thread
     constexpr int XVN = (BC * XWP + NTH - 1) / NTH; // staged X floats per thread
     static_assert(BM * BKT % NTH == 0, "A tile must split evenly");
+    static_assert(!VEC || (AVN % 4 == 0 && (BC * XWP) % (4 * NTH) == 0), "vector staging must split evenly");
     typedef typename FVec<AVN>::type avec_t;
     typedef typename FVec<XVN>::type xvec_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -54,7 +57,9 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
     const int wm = wave / WC, wc = wave % WC;
     const int nl = lane & 31, h = lane >> 5;
 
+    constexpr int HP = (XWP - BKT) / 2;        // window start = t0 - HP
     const int halo = (KS >> 1) * a.dil;
+    const int xoff = HP - halo;                // column of tap 0 inside the window
     float* As = smem;                          // [BM][PA]
     float* Xs = smem + BM * PA;                // [BC][PX]
 
@@ -97,26 +102,63 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
         if (a.order) sidx = a.order[sidx];                                                        \
         const float* ab = a.a + (long)sidx * a.a_sstride;                                         \
         const float* xb = a.x + (long)sidx * a.x_sstride;                                         \
-        _Pragma("unroll") for (int k = 0; k < AVN; ++k) {                                         \
-            const int i = (tid >> 5) + k * (NTH / 32);                                            \
-            const int m = m0 + i, t = t0 + (tid & 31);                                            \
-            areg[k] = (m < a.M && t < a.T) ? ab[(long)m * a.a_rstride + t] : 0.f;                 \
-        }                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < XVN; ++k) {                                         \
-            const int e = tid + k * NTH;                                                          \
-            const int i = e / XWP, xx = e - i * XWP;                                              \
-            const int c = c0 + i, t = t0 - halo + xx;                                             \
-            xreg[k] = (i < BC && c < a.Cn && t >= 0 && t < a.T) ? xb[(long)c * a.x_rstride + t] : 0.f; \
+        if constexpr (VEC) {                                                                      \
+            _Pragma("unroll") for (int k = 0; k < AVN / 4; ++k) {                                 \
+                const int e = tid + k * NTH;                                                      \
+                const int i = e >> 3, q = e & 7;                                                  \
+                const int m = m0 + i, t = t0 + 4 * q;                                             \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+                if (m < a.M && t < a.T)                                                           \
+                    v = *reinterpret_cast<const float4*>(ab + (long)m * a.a_rstride + t);         \
+                areg[4 * k] = v.x; areg[4 * k + 1] = v.y; areg[4 * k + 2] = v.z; areg[4 * k + 3] = v.w; \
+            }                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < XVN / 4; ++k) {                                 \
+                const int e = tid + k * NTH;                                                      \
+                const int i = e / (XWP / 4), q = e - i * (XWP / 4);                               \
+                const int c = c0 + i, t = t0 - HP + 4 * q;                                        \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+                if (i < BC && c < a.Cn && t >= 0 && t < a.T)                                      \
+                    v = *reinterpret_cast<const float4*>(xb + (long)c * a.x_rstride + t);         \
+                xreg[4 * k] = v.x; xreg[4 * k + 1] = v.y; xreg[4 * k + 2] = v.z; xreg[4 * k + 3] = v.w; \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < AVN; ++k) {                                     \
+                const int i = (tid >> 5) + k * (NTH / 32);                                        \
+                const int m = m0 + i, t = t0 + (tid & 31);                                        \
+                areg[k] = (m < a.M && t < a.T) ? ab[(long)m * a.a_rstride + t] : 0.f;             \
+            }                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < XVN; ++k) {                                     \
+                const int e = tid + k * NTH;                                                      \
+                const int i = e / XWP, xx = e - i * XWP;                                          \
+                const int c = c0 + i, t = t0 - HP + xx;                                           \
+                xreg[k] = (i < BC && c < a.Cn && t >= 0 && t < a.T) ? xb[(long)c * a.x_rstride + t] : 0.f; \
+            }                                                                                     \
         }                                                                                         \
     }
 #define NT_STORE()                                                                                \
     {                                                                                             \
-        _Pragma("unroll") for (int k = 0; k < AVN; ++k)                                           \
-            As[((tid >> 5) + k * (NTH / 32)) * PA + (tid & 31)] = areg[k];                        \
-        _Pragma("unroll") for (int k = 0; k < XVN; ++k) {                                         \
-            const int e = tid + k * NTH;                                                          \
-            const int i = e / XWP, xx = e - i * XWP;                                              \
-            if (i < BC) Xs[i * PX + xx] = xreg[k];                                                \
+        if constexpr (VEC) {                                                                      \
+            _Pragma("unroll") for (int k = 0; k < AVN / 4; ++k) {                                 \
+                const int e = tid + k * NTH;                                                      \
+                float* d = As + (e >> 3) * PA + 4 * (e & 7);                                      \
+                d[0] = areg[4 * k]; d[1] = areg[4 * k + 1]; d[2] = areg[4 * k + 2]; d[3] = areg[4 * k + 3]; \
+            }                                                                                     \
+            _Pragma("unroll") for (int k = 0; k < XVN / 4; ++k) {                                 \
+                const int e = tid + k * NTH;                                                      \
+                const int i = e / (XWP / 4), q = e - i * (XWP / 4);                               \
+                if (i < BC) {                                                                     \
+                    float* d = Xs + i * PX + 4 * q;                                               \
+                    d[0] = xreg[4 * k]; d[1] = xreg[4 * k + 1]; d[2] = xreg[4 * k + 2]; d[3] = xreg[4 * k + 3]; \
+                }                                                                                 \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < AVN; ++k)                                       \
+                As[((tid >> 5) + k * (NTH / 32)) * PA + (tid & 31)] = areg[k];                    \
+            _Pragma("unroll") for (int k = 0; k < XVN; ++k) {                                     \
+                const int e = tid + k * NTH;                                                      \
+                const int i = e / XWP, xx = e - i * XWP;                                          \
+                if (i < BC) Xs[i * PX + xx] = xreg[k];                                            \
+            }                                                                                     \
         }                                                                                         \
     }
 
@@ -138,7 +180,7 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
         _Pragma("unroll") for (int i = 0; i < MT; ++i) av[i] = ap[i * 32 * PA + 2 * (KK_)];       \
         _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                          \
             _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                      \
-                const float bv = xp[k * 32 * PX + 2 * (KK_) + j * a.dil];                         \
+                const float bv = xp[k * 32 * PX + 2 * (KK_) + xoff + j * a.dil];                         \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][k][j] =                     \
                     __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][k][j], 0, 0, 0);       \
             }                                                                                     \
@@ -183,12 +225,12 @@ __global__ __launch_bounds__(WM * WC * 64) void gemm_nt_kernel(GemmNTArgs a) {
         }
 }
 
-template <int WM, int WC, int MT, int NT, int KS, int XWP>
-static int launch_gemm_nt_w(GemmNTArgs a, hipStream_t stream) {
+template <int WM, int WC, int MT, int NT, int KS, int XWP, bool VEC>
+static int launch_gemm_nt_v(GemmNTArgs a, hipStream_t stream) {
     constexpr int BM = WM * MT * 32, BC = WC * NT * 32;
     const size_t lds = (size_t)(BM * (BKT + 1) + BC * (XWP + 1)) * sizeof(float);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<WM, WC, MT, NT, KS, XWP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<WM, WC, MT, NT, KS, XWP, VEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
@@ -196,9 +238,19 @@ static int launch_gemm_nt_w(GemmNTArgs a, hipStream_t stream) {
     a.tiles_c = cdiv(a.Cn, BC);
     const long nblocks = (long)a.tiles_m * a.tiles_c * a.nsplit * a.G;
     if (nblocks <= 0) return BM_OK;
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WC, MT, NT, KS, XWP>), dim3((unsigned)nblocks),
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WC, MT, NT, KS, XWP, VEC>), dim3((unsigned)nblocks),
                        dim3(WM * WC * 64), lds, stream, a);
     return bm_check_launch("gemm_nt");
+}
+
+template <int WM, int WC, int MT, int NT, int KS, int XWP>
+static int launch_gemm_nt_w(GemmNTArgs a, hipStream_t stream) {
+    // dwordx4 staging needs every row start 16-byte aligned and T a multiple of 4
+    const bool vec = (a.T % 4 == 0) && (a.a_rstride % 4 == 0) && (a.x_rstride % 4 == 0) &&
+                     (a.a_sstride % 4 == 0) && (a.x_sstride % 4 == 0) &&
+                     (((uintptr_t)a.a | (uintptr_t)a.x) % 16 == 0);
+    if (vec) return launch_gemm_nt_v<WM, WC, MT, NT, KS, XWP, true>(a, stream);
+    return launch_gemm_nt_v<WM, WC, MT, NT, KS, XWP, false>(a, stream);
 }
 
 template <int WM, int WC, int MT, int NT, int KS>

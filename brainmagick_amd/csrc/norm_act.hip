@@ -359,6 +359,49 @@ extern "C" int bm_channel_sum(const float* x, long bstride, float* out, void* wo
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-channel (sum, sumsq) partials of the conv output for BatchNorm1d (train mode), one streaming
+// pass; written in the [nsplit][C][2] layout that bn_finalize folds.  (Cheaper than reducing the
+// MFMA accumulators across lanes in the conv epilogue: 24 us vs ~70 us per 320-channel layer.)
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ stats, int B, int C,
+                                                            int T) {
+    __shared__ double sh[4 * 2];
+    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const int TV = T / VEC;
+    float s = 0.f, s2 = 0.f;
+    const long nloc = (long)(b1 - b0) * TV;
+    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
+        const int bl = (int)(e / TV);
+        const int tv = (int)(e - (long)bl * TV);
+        const Pack<VEC> v = Pack<VEC>::ld(x + ((long)(b0 + bl) * C + c) * T + (long)tv * VEC);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s += v.v[i]; s2 += v.v[i] * v.v[i]; }
+    }
+    double acc[2] = {(double)s, (double)s2};
+    block_sum<2>(acc, sh);
+    if (threadIdx.x == 0) {
+        stats[((long)split * C + c) * 2 + 0] = (float)acc[0];
+        stats[((long)split * C + c) * 2 + 1] = (float)acc[1];
+    }
+}
+
+extern "C" int bm_channel_stats_splits(int B) { return B >= 64 ? 16 : (B >= 8 ? 4 : 1); }
+
+extern "C" int bm_channel_stats(const float* x, float* stats, int B, int C, int T, void* stream) {
+    BM_REQUIRE(x && stats, "channel_stats: null pointer");
+    const int nsplit = bm_channel_stats_splits(B);
+    hipStream_t s = (hipStream_t)stream;
+    if (T % 4 == 0)
+        hipLaunchKernelGGL(channel_stats_kernel<4>, dim3(C, nsplit), dim3(256), 0, s, x, stats, B, C, T);
+    else
+        hipLaunchKernelGGL(channel_stats_kernel<1>, dim3(C, nsplit), dim3(256), 0, s, x, stats, B, C, T);
+    return bm_check_launch("channel_stats");
+}
+
+// ------------------------------------------------------------------------------------------------
 // GLU(dim=1): out[b][h][t] = u[b][h][t] * sigmoid(u[b][H+h][t])      (bm/models/common.py:135)
 // ------------------------------------------------------------------------------------------------
 template <int VEC>

@@ -11,6 +11,12 @@ import torch
 
 from . import hip_ops as H
 
+import os
+
+# A/B switch (measurement only): BatchNorm partial statistics from the conv epilogue instead of the
+# separate streaming pass.
+_STATS_IN_EPILOGUE = os.environ.get("BM_STATS_IN_EPILOGUE", "0") == "1"
+
 ACT_CODES = {"none": H.ACT_NONE, "gelu": H.ACT_GELU, "relu": H.ACT_RELU, "leaky": H.ACT_LEAKY}
 
 
@@ -82,8 +88,8 @@ class ConvBNActFn(torch.autograd.Function):
     """One ConvSequence layer: Conv1d -> BatchNorm1d -> activation [-> + input] as fused HIP
     kernels (bm/models/common.py:113-119 + :146-147).
 
-    train: conv_nn (epilogue emits per-tile channel statistics) -> bn_finalize (also updates the
-    running statistics like torch) -> affine_act_res.  eval: ONE conv_nn launch with the affine,
+    train: conv_nn -> channel_stats (one streaming pass) -> bn_finalize (also updates the running
+    statistics like torch) -> affine_act_res.  eval: ONE conv_nn launch with the affine,
     activation and residual folded in its epilogue."""
 
     @staticmethod
@@ -97,8 +103,12 @@ class ConvBNActFn(torch.autograd.Function):
         res = x if residual else None
         needs_grad = x.requires_grad or weight.requires_grad
         if training:
-            pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False,
-                                      want_stats=True)
+            if _STATS_IN_EPILOGUE:
+                pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True,
+                                          want_out=False, want_stats=True)
+            else:
+                pre, _, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False)
+                stats = H.channel_stats(pre)
             mean, invstd, scale, shift = H.bn_finalize(stats, B * T, gamma, beta, running_mean,
                                                        running_var, num_batches, momentum, eps)
             out = H.affine_act_res(pre, scale, shift, res, act, leak)

@@ -276,6 +276,15 @@ def channel_sum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def channel_stats(x: torch.Tensor) -> torch.Tensor:
+    """[B, C, T] -> per-split (sum, sumsq) partials [nsplit, C, 2] for bn_finalize."""
+    _req(x, "channel_stats.x")
+    B, C, T = x.shape
+    stats = torch.empty(lib().bm_channel_stats_splits(B), C, 2, device=x.device, dtype=torch.float32)
+    check(lib().bm_channel_stats(_p(x), _p(stats), B, C, T, _stream()), "bm_channel_stats")
+    return stats
+
+
 def glu_fwd(u: torch.Tensor) -> torch.Tensor:
     _req(u, "glu_fwd.u")
     B, C2, T = u.shape

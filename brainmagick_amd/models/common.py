@@ -190,6 +190,7 @@ class PositionGetter:
     def __init__(self) -> None:
         self._cache: tp.Dict[int, torch.Tensor] = {}
         self._invalid_names: tp.Set[str] = set()
+        self._device_cache: tp.Dict[tp.Any, tp.Tuple[torch.Tensor, torch.Tensor]] = {}
 
     def get_recording_layout(self, recording) -> torch.Tensor:
         index = recording.recording_index
@@ -231,7 +232,15 @@ class PositionGetter:
         return positions
 
     def get_unique_layouts(self, batch, n_channels: int, device):
-        """-> (positions_u [U, C, 2] on device, layout_index [B] int64 on device)."""
+        """-> (positions_u [U, C, 2] on device, layout_index [B] int64 on device).
+
+        The device tensors are cached per (recording-index tuple, C, device): a training loop that
+        revisits the same recordings does not re-upload layouts every step."""
+        key = (tuple(batch._recordings[i].recording_index for i in range(len(batch))), n_channels,
+               str(device))
+        hit = self._device_cache.get(key)
+        if hit is not None:
+            return hit
         slots: tp.Dict[int, int] = {}
         rows: tp.List[torch.Tensor] = []
         index: tp.List[int] = []
@@ -247,6 +256,9 @@ class PositionGetter:
             index.append(slots[key])
         positions_u = torch.stack(rows).to(device)
         layout_index = torch.tensor(index, dtype=torch.int64).to(device)
+        if len(self._device_cache) >= 64:
+            self._device_cache.pop(next(iter(self._device_cache)))
+        self._device_cache[key] = (positions_u, layout_index)
         return positions_u, layout_index
 
     def is_invalid(self, positions):

@@ -86,6 +86,9 @@ int bm_act_bn_bwd(const float* dout, const float* y, const float* scale, const f
 long bm_channel_sum_workspace_bytes(int B, int C);
 int bm_channel_sum(const float* x, long bstride, float* out, void* workspace, long workspace_bytes,
                    int B, int C, int T, void* stream);
+/* one-pass per-channel (sum, sumsq) partials [nsplit][C][2] of a conv output, folded by bm_bn_finalize */
+int bm_channel_stats_splits(int B);
+int bm_channel_stats(const float* x, float* stats, int B, int C, int T, void* stream);
 int bm_glu_fwd(const float* u, float* out, int B, int H, int T, void* stream);
 long bm_glu_bwd_workspace_bytes(int B, int H);
 int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
