@@ -362,6 +362,23 @@ def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
     return scores, probs, dscaled, loss
 
 
+def center_scale(x: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
+                 group: tp.Optional[torch.Tensor] = None, clip: bool = False, limit: float = 0.,
+                 want_maxabs: bool = False, inplace: bool = False):
+    """(x - center[group[b]]) / scale[group[b]] [clamped]; returns (out, maxabs [B] | None)."""
+    _req(x, "center_scale.x")
+    _req(center, "center_scale.center")
+    _req(scale, "center_scale.scale")
+    B, C, T = x.shape
+    assert center.shape[-1] == C and scale.shape == center.shape
+    out = x if inplace else torch.empty_like(x)
+    maxabs = torch.zeros(B, device=x.device, dtype=torch.float32) if want_maxabs else None
+    check(lib().bm_center_scale(_p(x), _p(out), _p(_opt(group, "group", torch.int64)), _p(center),
+                                _p(scale), B, C, T, int(clip), float(limit), _p(maxabs), _stream()),
+          "bm_center_scale")
+    return out, maxabs
+
+
 def topk_rows(x: torch.Tensor, k: int, col_labels=None, row_labels=None):
     """x [N, V] -> (idx [N, k] int32, values [N, k], hits [N] int32 | None)."""
     _req(x, "topk_rows.x")

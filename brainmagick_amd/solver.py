@@ -23,7 +23,7 @@ class Solver:
     def __init__(self, model: torch.nn.Module, loss: tp.Optional[ClipLoss] = None,
                  optimizer: tp.Optional[FlatAdam] = None, device: str = "cuda",
                  offset_meg_ms: float = 0., sample_rate: float = 120., negatives: str = "local",
-                 lr: float = 3e-4, betas=(0.9, 0.999)):
+                 lr: float = 3e-4, betas=(0.9, 0.999), scale_reject=None):
         assert negatives in ("local", "node")
         self.device = torch.device(device)
         self.model = model.to(self.device)
@@ -37,11 +37,15 @@ class Solver:
         self.sample_rate = sample_rate
         self.negatives = negatives
         self._gather = distrib.CandidateGather() if negatives == "node" else None
+        self.scale_reject = scale_reject          # brainmagick_amd.norm.ScaleReject or None
 
     # -- bm/solver.py:230-321 ------------------------------------------------------------------
     def _process_batch(self, batch, training: bool = False):
         batch = batch.to(self.device)
-        reject_mask = torch.ones(len(batch.meg), dtype=torch.bool, device=self.device)
+        if self.scale_reject:
+            batch, reject_mask = self.scale_reject(batch)          # bm/solver.py:245-246
+        else:
+            reject_mask = torch.ones(len(batch.meg), dtype=torch.bool, device=self.device)
         meg = batch.meg
         features = batch.features
         features_mask = batch.features_mask

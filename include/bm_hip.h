@@ -94,6 +94,12 @@ long bm_glu_bwd_workspace_bytes(int B, int H);
 int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
                long workspace_bytes, int B, int H, int T, void* stream);
 
+/* ---- ScaleReject front end (scale.hip)  bm/norm.py:86-87,255-261,325-341; bm/solver.py:245-246 ----
+ * out = clamp((x - center[group[b]][c]) / scale[group[b]][c]); maxabs[b] = max|out[b]| (zero-init). */
+int bm_center_scale(const float* x, float* out, const long* group, const float* center,
+                    const float* scale, int B, int C, int T, int clip, float limit, float* maxabs,
+                    void* stream);
+
 /* ---- ChannelMerger front end (merger.hip)  bm/models/common.py:239-271,334-357 ---- */
 int bm_fourier_emb(const float* positions, float* emb, long rows, int D, float margin, void* stream);
 int bm_masked_softmax(const float* scores, const float* positions, const float* ban_center,

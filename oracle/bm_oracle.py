@@ -319,6 +319,30 @@ def topk_accuracy(probs: torch.Tensor, labels: torch.Tensor, row_labels: torch.T
 
 
 # ----------------------------------------------------------------------------------------------
+# ScaleReject front end
+# ----------------------------------------------------------------------------------------------
+def scale_reject(meg, features, recording_index, meg_center, meg_scale, feature_center=None,
+                 feature_scale=None, limit=16, clip=False):
+    """bm/norm.py:239-275 (BatchScaler._transform: per-segment RobustScaler.transform picked by
+    recording, :86-87) followed by bm/norm.py:325-341 (ScaleReject.__call__).  Returns
+    (meg, features, keep)."""
+    out = []
+    for entry_meg, entry_rec in zip(meg, recording_index):
+        r = int(entry_rec)
+        out.append(((entry_meg.t() - meg_center[r].to(entry_meg)) / meg_scale[r].to(entry_meg)).t())
+    meg = torch.stack(out)
+    if feature_center is not None:
+        x = features.permute(0, 2, 1).reshape(-1, features.shape[1])          # _as_nd, norm.py:23-26
+        x = (x - feature_center.to(x)) / feature_scale.to(x)
+        features = x.view(features.shape[0], features.shape[2], -1).permute(0, 2, 1).contiguous()
+    if clip:
+        meg = meg.clamp(-limit, limit)
+    reject = meg.abs().view(len(meg), -1).max(-1)[0] > limit
+    keep = ~reject
+    return meg[keep], features[keep], keep
+
+
+# ----------------------------------------------------------------------------------------------
 # Optimiser step and the solver's step body
 # ----------------------------------------------------------------------------------------------
 def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr=3e-4, beta1=0.9, beta2=0.999,

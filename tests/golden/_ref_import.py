@@ -45,3 +45,27 @@ def load_reference():
         spec.loader.exec_module(losses)
     losses = sys.modules["bm_ref_losses"]
     return simpleconv, common, losses
+
+
+def load_reference_norm():
+    """bm/norm.py under stubs for its three imports (dora.log, .features, .dataset)."""
+    load_reference()
+    if "bm.norm" not in sys.modules:
+        dora = types.ModuleType("dora")
+        dora_log = types.ModuleType("dora.log")
+        dora_log.LogProgress = object
+        dora.log = dora_log
+        sys.modules.setdefault("dora", dora)
+        sys.modules.setdefault("dora.log", dora_log)
+        feats = types.ModuleType("bm.features")
+        feats.FeaturesBuilder = object
+        feats.Feature = object
+        dset = types.ModuleType("bm.dataset")
+        dset.SegmentBatch = object
+        sys.modules["bm.features"] = feats
+        sys.modules["bm.dataset"] = dset
+        spec = importlib.util.spec_from_file_location("bm.norm", REF / "bm" / "norm.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["bm.norm"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["bm.norm"]

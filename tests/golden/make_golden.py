@@ -21,7 +21,7 @@ HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE))
 sys.path.insert(0, str(HERE.parent.parent))
 
-from _ref_import import load_reference  # noqa: E402
+from _ref_import import load_reference, load_reference_norm  # noqa: E402
 from brainmagick_amd.synthetic import make_batch  # noqa: E402
 
 SMALL = dict(C=20, T=48, F=10, S=5, B=6)
@@ -193,7 +193,72 @@ def clip_only_fixture(losses):
     return out
 
 
+def scale_reject_fixture():
+    """bm/norm.py BatchScaler._transform + ScaleReject.__call__ of the live reference."""
+    import collections
+    norm = load_reference_norm()
+    gen = torch.Generator().manual_seed(4242)
+    B, C, T, Fd, R = 10, 14, 40, 6, 3
+    meg = torch.randn(B, C, T, generator=gen) * 4 + 0.3
+    meg[1, 3, 7] = 400.0
+    meg[6, 0, 0] = -250.0
+    features = torch.randn(B, Fd, T, generator=gen) * 2 + 1
+    rec = torch.randint(0, R, (B,), generator=gen)
+
+    class FB:                                   # the FeaturesBuilder surface _transform touches
+        dimension = Fd
+
+        def get_slice(self, name):
+            return {"a": slice(0, 4), "b": slice(4, 6)}[name]
+
+        def items(self):
+            return []
+
+    class Batch:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def replace(self, **kw):
+            d = dict(self.__dict__)
+            d.update(kw)
+            return Batch(**d)
+
+        def __getitem__(self, keep):
+            return Batch(meg=self.meg[keep], features=self.features[keep],
+                         features_mask=self.features_mask[keep],
+                         recording_index=self.recording_index[keep])
+
+    scaler = norm.BatchScaler.__new__(norm.BatchScaler)
+    scaler.features_builder = FB()
+    scaler.meg_scalers = {}
+    centers, scales = torch.zeros(R, C), torch.ones(R, C)
+    for r in range(R):
+        rs = norm.RobustScaler()
+        rs.fit(torch.randn(500, C, generator=gen) * (r + 1) + 0.1 * r)
+        scaler.meg_scalers[r] = rs
+        centers[r], scales[r] = rs.center_, rs.scale_
+    fa, fb = norm.StandardScaler(per_channel=True), norm.NoOpScaler()
+    fa.fit(torch.randn(300, 4, generator=gen) * 2 + 1, torch.ones(300, 1, dtype=torch.bool))
+    scaler.feature_scalers = collections.OrderedDict(a=fa, b=fb)
+    out = {"in/meg": meg.numpy().copy(), "in/features": features.numpy().copy(),
+           "in/recording_index": rec.numpy().copy(), "in/meg_center": centers.numpy().copy(),
+           "in/meg_scale": scales.numpy().copy(),
+           "in/feature_center": torch.cat([fa.center_, torch.zeros(2)]).numpy().copy(),
+           "in/feature_scale": torch.cat([fa.scale_, torch.ones(2)]).numpy().copy()}
+    for tag, clip in (("clip", True), ("reject", False)):
+        batch = Batch(meg=meg.clone(), features=features.clone(),
+                      features_mask=torch.ones(B, 1, T, dtype=torch.bool), recording_index=rec)
+        sr = norm.ScaleReject(scaler, limit=20, clip=clip)
+        res, keep = sr(batch)
+        out[f"{tag}/meg"] = res.meg.numpy().copy()
+        out[f"{tag}/features"] = res.features.numpy().copy()
+        out[f"{tag}/keep"] = keep.numpy().copy()
+    return out
+
+
 def main():
+    np.savez_compressed(HERE / "scale_reject.npz", **scale_reject_fixture())
+    print("scale_reject: done")
     sc, common, losses = load_reference()
     for name, spec in VARIANTS.items():
         out = run_variant(name, spec, sc, common, losses)

@@ -90,3 +90,17 @@ def test_topk_accuracy_rule():
     labels = torch.tensor([0, 1, 2])
     assert O.topk_accuracy(probs, labels, labels, topk=1) == pytest.approx(1 / 3)
     assert O.topk_accuracy(probs, labels, labels, topk=2) == pytest.approx(2 / 3)
+
+
+@pytest.mark.parametrize("tag,clip", [("clip", True), ("reject", False)])
+def test_scale_reject_oracle_matches_reference(tag, clip):
+    """oracle.scale_reject vs the live reference's BatchScaler._transform + ScaleReject."""
+    g = Golden("scale_reject")
+    meg, feats, keep = O.scale_reject(g.t("in/meg"), g.t("in/features"), g.t("in/recording_index"),
+                                      g.t("in/meg_center"), g.t("in/meg_scale"),
+                                      g.t("in/feature_center"), g.t("in/feature_scale"), limit=20,
+                                      clip=clip)
+    assert torch.equal(keep, g.t(f"{tag}/keep"))
+    assert torch.equal(meg, g.t(f"{tag}/meg"))
+    assert torch.equal(feats, g.t(f"{tag}/features"))
+    assert clip or int((~keep).sum()) == 2
