@@ -157,3 +157,62 @@ extern "C" int bm_topk_rows(const float* x, int rows, int cols, int k, int* idx_
                        cols, k, idx_out, val_out, col_labels, row_labels, hit_out);
     return bm_check_launch("topk_rows");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Gradient of ClipLoss w.r.t. the CANDIDATES (learnable feature model, bm/solver.py:304-320 +
+// bm/models/features.py DeepMel):  with s[b,o] = inv_o * <est_b, cand_o>,  inv_o = 1/(1e-8+|cand_o|)
+//   dcand_o = sum_b dscaled[b,o] * est_b  -  coef_o * cand_o,
+//   coef_o  = (sum_b dscaled[b,o] * s[b,o]) / |cand_o|
+// The first term is an MFMA GEMM (conv_nn.hip); this file provides coef and the rank-1 correction.
+// ------------------------------------------------------------------------------------------------
+__global__ void clip_cand_coef_kernel(const float* __restrict__ dscaled, const float* __restrict__ scores,
+                                      const float* __restrict__ inv_norm, const float* __restrict__ alpha,
+                                      float* __restrict__ coef, int B, int Bc) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= Bc) return;
+    double r = 0;
+    for (int b = 0; b < B; ++b) r += (double)dscaled[(long)b * Bc + o] * (double)scores[(long)b * Bc + o];
+    const float norm = 1.0f / inv_norm[o] - 1e-8f;
+    const float a = alpha ? *alpha : 1.f;
+    coef[o] = norm > 0.f ? a * (float)r / norm : 0.f;
+}
+
+extern "C" int bm_clip_cand_coef(const float* dscaled, const float* scores, const float* inv_norm,
+                                 const float* alpha, float* coef, int B, int Bc, void* stream) {
+    BM_REQUIRE(dscaled && scores && inv_norm && coef, "clip_cand_coef: null pointer");
+    if (Bc == 0) return BM_OK;
+    hipLaunchKernelGGL(clip_cand_coef_kernel, dim3((Bc + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       dscaled, scores, inv_norm, alpha, coef, B, Bc);
+    return bm_check_launch("clip_cand_coef");
+}
+
+// y[r][i] -= coef[r] * x[r][i]
+__global__ void row_axpy_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                const float* __restrict__ coef, long K, long K4) {
+    const int r = blockIdx.y;
+    const float c = coef[r];
+    float* yr = y + (long)r * K;
+    const float* xr = x + (long)r * K;
+    if (K4) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < K4; i += (long)gridDim.x * blockDim.x) {
+            float4 a = reinterpret_cast<float4*>(yr)[i];
+            const float4 b = reinterpret_cast<const float4*>(xr)[i];
+            a.x -= c * b.x; a.y -= c * b.y; a.z -= c * b.z; a.w -= c * b.w;
+            reinterpret_cast<float4*>(yr)[i] = a;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < K; i += (long)gridDim.x * blockDim.x)
+            yr[i] -= c * xr[i];
+    }
+}
+
+extern "C" int bm_row_axpy_sub(float* y, const float* x, const float* coef, int rows, long K, void* stream) {
+    BM_REQUIRE(y && x && coef, "row_axpy_sub: null pointer");
+    if (rows == 0 || K == 0) return BM_OK;
+    const long K4 = (K % 4 == 0 && (((uintptr_t)y | (uintptr_t)x) % 16 == 0)) ? K / 4 : 0;
+    const long n = K4 ? K4 : K;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(row_axpy_kernel, dim3(bx, rows), dim3(256), 0, (hipStream_t)stream, y, x, coef, K, K4);
+    return bm_check_launch("row_axpy_sub");
+}

@@ -171,3 +171,38 @@ class CandidateGather:
         if self.stream is not None and out.is_cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         return out, rank() * self._B
+
+
+class GatherCandidatesFn(torch.autograd.Function):
+    """All-gather of LEARNABLE candidates (feature model on, bm/solver.py:304-320) with its adjoint:
+    the gradient of the gathered tensor is reduce-scattered (summed over ranks) back to the owner of
+    each block.  Together with the mean-over-ranks of parameter gradients this yields the gradient
+    of the mean of the per-rank losses."""
+
+    @staticmethod
+    def forward(ctx, candidates):
+        world = world_size()
+        candidates = candidates.contiguous()
+        out = torch.empty((world * candidates.shape[0],) + tuple(candidates.shape[1:]),
+                          device=candidates.device, dtype=candidates.dtype)
+        dist.all_gather_into_tensor(out, candidates)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        world, r = world_size(), rank()
+        grad = grad.contiguous()
+        B = grad.shape[0] // world
+        if dist.get_backend() == "gloo":
+            dist.all_reduce(grad)
+            return grad[r * B:(r + 1) * B].clone()
+        out = torch.empty((B,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
+        dist.reduce_scatter_tensor(out, grad)
+        return out
+
+
+def gather_learnable_candidates(candidates: torch.Tensor):
+    """-> (gathered [world*B, ...], target_offset); identity at world_size 1."""
+    if not is_distributed():
+        return candidates, 0
+    return GatherCandidatesFn.apply(candidates), rank() * candidates.shape[0]

@@ -260,22 +260,36 @@ class ClipLossFn(torch.autograd.Function):
         part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
         scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True,
                                              target_offset=target_offset)
-        ctx.save_for_backward(candidate, dscaled)
+        if ctx.needs_input_grad[1]:
+            ctx.save_for_backward(candidate, dscaled, estimate, scores, inv)
+        else:
+            ctx.save_for_backward(candidate, dscaled)
         ctx.shape = estimate.shape
+        ctx.cand_shape = candidate.shape
         ctx.mark_non_differentiable(scores)
         return loss, scores
 
     @staticmethod
     def backward(ctx, dloss, _dscores):
-        candidate, dscaled = ctx.saved_tensors
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("ClipLoss: gradients w.r.t. candidates (learnable feature "
-                                      "model) are not implemented on the HIP path yet")
+        candidate, dscaled = ctx.saved_tensors[:2]
         B, Bc = dscaled.shape
         K = candidate.numel() // Bc
-        wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=_c(dloss).view(1))
-        _, dest, _ = H.conv_nn(candidate.view(1, Bc, K), wp, B, 1, 1)
-        return dest.view(ctx.shape), None, None
+        alpha = _c(dloss).view(1)
+        dest = None
+        if ctx.needs_input_grad[0]:
+            wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=alpha)
+            _, dest, _ = H.conv_nn(candidate.view(1, Bc, K), wp, B, 1, 1)
+            dest = dest.view(ctx.shape)
+        dcand = None
+        if ctx.needs_input_grad[1]:
+            # learnable candidates (DeepMel feature model): dcand_o = sum_b dscaled[b,o] est_b - coef_o cand_o
+            estimate, scores, inv = ctx.saved_tensors[2:]
+            wpt = H.pack_weights(dscaled, 1, Bc, B, 1, 0, 1, Bc, 0, alpha=alpha)
+            _, dcand, _ = H.conv_nn(estimate.view(1, B, K), wpt, Bc, 1, 1)
+            coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
+            H.row_axpy_sub(dcand.view(Bc, K), candidate.view(Bc, K), coef)
+            dcand = dcand.view(ctx.cand_shape)
+        return dest, dcand, None
 
 
 def clip_scores(estimate, candidate, want_probs=False):

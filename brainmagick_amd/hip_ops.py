@@ -362,6 +362,27 @@ def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
     return scores, probs, dscaled, loss
 
 
+def clip_cand_coef(dscaled, scores, inv_norm, alpha=None) -> torch.Tensor:
+    _req(dscaled, "clip_cand_coef.dscaled")
+    _req(scores, "clip_cand_coef.scores")
+    B, Bc = dscaled.shape
+    coef = torch.empty(Bc, device=dscaled.device, dtype=torch.float32)
+    check(lib().bm_clip_cand_coef(_p(dscaled), _p(scores), _p(_req(inv_norm, "inv_norm")),
+                                  _p(_opt(alpha, "alpha")), _p(coef), B, Bc, _stream()),
+          "bm_clip_cand_coef")
+    return coef
+
+
+def row_axpy_sub(y: torch.Tensor, x: torch.Tensor, coef: torch.Tensor):
+    """y[r] -= coef[r] * x[r] (in place), rows = first dimension."""
+    _req(y, "row_axpy_sub.y")
+    _req(x, "row_axpy_sub.x")
+    rows = y.shape[0]
+    check(lib().bm_row_axpy_sub(_p(y), _p(x), _p(_req(coef, "coef")), rows, y.numel() // max(rows, 1),
+                                _stream()), "bm_row_axpy_sub")
+    return y
+
+
 def center_scale(x: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
                  group: tp.Optional[torch.Tensor] = None, clip: bool = False, limit: float = 0.,
                  want_maxabs: bool = False, inplace: bool = False):

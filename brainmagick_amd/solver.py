@@ -23,14 +23,18 @@ class Solver:
     def __init__(self, model: torch.nn.Module, loss: tp.Optional[ClipLoss] = None,
                  optimizer: tp.Optional[FlatAdam] = None, device: str = "cuda",
                  offset_meg_ms: float = 0., sample_rate: float = 120., negatives: str = "local",
-                 lr: float = 3e-4, betas=(0.9, 0.999), scale_reject=None):
+                 lr: float = 3e-4, betas=(0.9, 0.999), scale_reject=None,
+                 feature_model: tp.Optional[torch.nn.Module] = None):
         assert negatives in ("local", "node")
         self.device = torch.device(device)
         self.model = model.to(self.device)
         self.loss = (loss or ClipLoss()).to(self.device)
+        self.feature_model = feature_model.to(self.device) if feature_model is not None else None
         world = distrib.world_size()
         if optimizer is None:
             params = list(self.model.parameters()) + list(self.loss.parameters())
+            if self.feature_model is not None:
+                params += list(self.feature_model.parameters())       # bm/train.py:116-117
             optimizer = FlatAdam(params, lr=lr, betas=betas, pad_to=max(world, 1) * 4)
         self.optimizer = optimizer
         self.offset_meg_ms = offset_meg_ms
@@ -57,21 +61,34 @@ class Solver:
             meg = meg[..., offset:]
             features = features[..., :-offset]
             features_mask = features_mask[..., :-offset]
-        if self._gather is not None:
+        if self._gather is not None and self.feature_model is None:
             # candidates do not depend on the model: start the xGMI all-gather before the encoder
             self._gather.start(features.contiguous())
         inputs = dict(meg=meg.contiguous())
         estimate = self.model(inputs, batch)
+        if self.feature_model is not None:
+            features = self.feature_model(features.contiguous())      # bm/solver.py:304-320
         return estimate, features, features_mask, reject_mask
+
+    def _all_models(self):
+        return [self.model] + ([self.feature_model] if self.feature_model is not None else [])
+
+    def _candidates(self, output):
+        """(candidates, target_offset): local, gathered on the side stream (constant candidates) or
+        gathered with an autograd-aware all-gather (learnable candidates)."""
+        if self.negatives != "node":
+            return output, 0
+        if self.feature_model is None:
+            return self._gather.wait()
+        return distrib.gather_learnable_candidates(output)
 
     # -- bm/solver.py:343-390 (one iteration) -----------------------------------------------------
     def train_step(self, batch) -> torch.Tensor:
-        self.model.train(True)
+        for m in self._all_models():
+            m.train(True)
         self.loss.train(True)
         estimate, output, features_mask, _ = self._process_batch(batch, training=True)
-        target_offset = 0
-        if self._gather is not None:
-            output, target_offset = self._gather.wait()
+        output, target_offset = self._candidates(output)
         loss = self.loss(estimate, output, features_mask, target_offset=target_offset)
         # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path
         # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
@@ -82,19 +99,19 @@ class Solver:
 
     @torch.no_grad()
     def eval_step(self, batch) -> torch.Tensor:
-        self.model.train(False)
+        for m in self._all_models():
+            m.train(False)
         self.loss.train(False)
         estimate, output, features_mask, _ = self._process_batch(batch, training=False)
-        target_offset = 0
-        if self._gather is not None:
-            output, target_offset = self._gather.wait()
+        output, target_offset = self._candidates(output)
         return self.loss(estimate, output, features_mask, target_offset=target_offset)
 
     @torch.no_grad()
     def predict(self, batch):
         """(estimate, candidates) for retrieval evaluation (bm/wer.py:52, run_eval_probs.py:102)."""
-        self.model.train(False)
+        for m in self._all_models():
+            m.train(False)
         estimate, output, _, _ = self._process_batch(batch, training=False)
-        if self._gather is not None:
+        if self._gather is not None and self.feature_model is None:
             self._gather.wait()
         return estimate, output

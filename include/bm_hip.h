@@ -112,6 +112,11 @@ int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scor
                float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
                void* stream);
 
+/* Gradient of ClipLoss w.r.t. the candidates (learnable feature model, bm/solver.py:304-320):
+ * coef[o] = alpha * (sum_b dscaled[b,o]*scores[b,o]) / |cand_o| ;  y[r] -= coef[r] * x[r]. */
+int bm_clip_cand_coef(const float* dscaled, const float* scores, const float* inv_norm,
+                      const float* alpha, float* coef, int B, int Bc, void* stream);
+int bm_row_axpy_sub(float* y, const float* x, const float* coef, int rows, long K, void* stream);
 /* Retrieval evaluation: top-k columns per row + "own label among the top-k labels" hit flag.
  * Replaces probs.topk + label gather/compare of scripts/run_eval_probs.py:237-264 and bm/wer.py:104-111. */
 int bm_topk_rows(const float* x, int rows, int cols, int k, int* idx_out, float* val_out,

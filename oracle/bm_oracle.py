@@ -157,9 +157,10 @@ def conv_sequence(x: torch.Tensor, sd: dict, prefix: str, channels, cfg, trainin
     biased batch variance over (B,T) and updates running_var with the unbiased one."""
     assert cfg["groups"] == 1 and not cfg["rewrite"] and not cfg["post_skip"] \
         and cfg["scale"] is None and not cfg["conv_dropout"] and not cfg["dropout_input"]
+    dot = f"{prefix}." if prefix else ""
     for k, layer in enumerate(conv_sequence_plan(channels, cfg)):
         old_x = x
-        p = f"{prefix}.sequence.{k}"
+        p = f"{dot}sequence.{k}"
         x = F.conv1d(x, sd[f"{p}.0.weight"], sd[f"{p}.0.bias"], stride=1,
                      padding=layer["pad"], dilation=layer["dilation"])
         if layer["act"]:
@@ -178,7 +179,7 @@ def conv_sequence(x: torch.Tensor, sd: dict, prefix: str, channels, cfg, trainin
         if cfg["skip"] and x.shape == old_x.shape:
             x = x + old_x
         if layer["glu"]:
-            g = f"{prefix}.glus.{k}.0"
+            g = f"{dot}glus.{k}.0"
             x = F.conv1d(x, sd[f"{g}.weight"], sd[f"{g}.bias"], padding=cfg["glu_context"])
             x = F.glu(x, dim=1) if cfg["glu_glu"] else _activation(x, cfg)
     return x
@@ -269,6 +270,22 @@ def simpleconv_forward(sd: dict, cfg: dict, meg: torch.Tensor, positions: torch.
 # ----------------------------------------------------------------------------------------------
 # ClipLoss
 # ----------------------------------------------------------------------------------------------
+DEEP_MEL_CFG: tp.Dict[str, tp.Any] = dict(      # conf/feature_model/deep_mel.yaml
+    kernel_size=3, dilation_growth=2, dilation_period=5, batch_norm=True, skip=True, glu=2,
+    glu_context=1, glu_glu=True, gelu=False, relu_leakiness=0.0, groups=1, rewrite=False,
+    post_skip=False, scale=None, conv_dropout=0.0, dropout_input=0.0, _activation_on_last=False)
+
+
+def deep_mel_forward(sd: dict, features: torch.Tensor, n_hidden_channels: int, n_hidden_layers: int,
+                     n_out_channels: int, training: bool, cfg=None,
+                     new_buffers: tp.Optional[dict] = None) -> torch.Tensor:
+    """bm/models/features.py:15-35 DeepMel = ConvSequence([F] + [hidden]*(L-1) + [out]) with the
+    default activation LeakyReLU(0.0) (bm/models/common.py:97-98)."""
+    cfg = dict(DEEP_MEL_CFG if cfg is None else cfg)
+    channels = [features.shape[1]] + [n_hidden_channels] * (n_hidden_layers - 1) + [n_out_channels]
+    return conv_sequence(features, sd, "", channels, cfg, training, new_buffers)
+
+
 def clip_trim(estimates, candidates, tmin=None, tmax=None, dset_tmin=None, sample_rate=None):
     """bm/losses.py:50-75 ClipLoss.trim_samples (tmin/tmax already resolved for train/eval)."""
     if tmin is None:

@@ -157,6 +157,14 @@ assert abs(m["loss"] - (1 * 1 + 2 * 2) / 3) < 1e-9
 bn = torch.nn.BatchNorm1d(4); bn.running_mean.fill_(float(r))
 distrib.sync_buffers(bn)
 assert torch.allclose(bn.running_mean, torch.full((4,), 0.5))
+# learnable candidates: autograd-aware all-gather, gradient reduce-scattered back to the owner
+x = torch.full((2, 3), float(r + 1), requires_grad=True)
+gathered, off = distrib.gather_learnable_candidates(x)
+assert off == 2 * r and gathered.shape == (4, 3)
+wts = torch.arange(12.).view(4, 3) * (r + 1)
+(gathered * wts).sum().backward()
+expect = sum(torch.arange(12.).view(4, 3)[2 * r:2 * r + 2] * (k + 1) for k in range(w))
+assert torch.equal(x.grad, expect), (x.grad, expect)
 dist.barrier()
 print("WORKER_OK", r)
 '''

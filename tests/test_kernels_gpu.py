@@ -367,3 +367,19 @@ def test_scale_reject_against_reference_golden(H, tag, clip):
     assert torch.equal(keep.cpu(), g.t(f"{tag}/keep"))
     assert torch.equal(out.meg.cpu(), g.t(f"{tag}/meg"))
     assert torch.equal(out.features.cpu(), g.t(f"{tag}/features"))
+
+
+@pytest.mark.parametrize("B,Bc", [(6, 6), (5, 11)])
+def test_clip_loss_candidate_gradients(B, Bc):
+    """ClipLoss backward w.r.t. BOTH estimates and candidates (learnable feature model)."""
+    from brainmagick_amd.losses import ClipLoss
+    g = _gen(B * Bc)
+    est = torch.randn(B, 9, 40, generator=g, dtype=torch.float64, requires_grad=True)
+    cand = (torch.randn(Bc, 9, 40, generator=g, dtype=torch.float64) * 1.5).requires_grad_(True)
+    (O.clip_loss(est, cand) * 1.7).backward()
+    eg = est.detach().float().cuda().requires_grad_(True)
+    cg = cand.detach().float().cuda().requires_grad_(True)
+    loss = ClipLoss().cuda()(eg, cg, torch.ones(B, 1, 40, dtype=torch.bool, device="cuda"))
+    (loss * 1.7).backward()
+    assert rel_l2(eg.grad, est.grad) < GRAD_TOL
+    assert rel_l2(cg.grad, cand.grad) < GRAD_TOL

@@ -364,3 +364,42 @@ def test_training_curve_and_top10_parity():
         acc_ref = O.topk_accuracy(probs_ref, labels, labels, k)
         assert abs(acc_hip[f"top{k}"] - acc_ref) <= 0.01 + 1e-9, (k, acc_hip, acc_ref)
     assert acc_hip["top10"] > 5 * 10 / 256, "must beat chance (10/256) by a wide margin"
+
+
+def test_deep_mel_feature_model_step():
+    """Next row §8(f)#3: DeepMel (ConvSequence on the mel candidates) trained jointly with the
+    encoder; ClipLoss back-propagates into the candidates.  vs CPU oracle (torch autograd)."""
+    from brainmagick_amd.models import SimpleConv, DeepMel
+    from brainmagick_amd.solver import Solver
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=24, initial_linear=24, depth=4,
+               merger_dropout=0.0)
+    C, T, Fd, S, B, hidden, out_ch = 20, 64, 12, 3, 6, 32, 16
+    sb = synthetic.make_batch(B, C, T, Fd, S, seed=11)
+    torch.manual_seed(2)
+    model = SimpleConv(in_channels={"meg": C}, out_channels=out_ch, hidden={"meg": hidden},
+                       n_subjects=S, **cfg)
+    fm_kw = dict(n_hidden_channels=24, n_hidden_layers=4, n_out_channels=out_ch, kernel=3, stride=1,
+                 dilation_growth=2, dilation_period=5, batch_norm=True, activation_on_last=False,
+                 skip=True, glu_context=1, glu=2)
+    fmodel = DeepMel(n_in_channels=Fd, **fm_kw)
+    sd_m, sd_f = copy.deepcopy(model.state_dict()), copy.deepcopy(fmodel.state_dict())
+    solver = Solver(model, feature_model=fmodel)
+    loss = solver.train_step(sb)
+
+    # oracle: same two networks with torch autograd on CPU
+    om = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in sd_m.items()}
+    of = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in sd_f.items()}
+    est = O.simpleconv_forward(om, cfg, sb.meg, sb.positions(), sb.subject_index, hidden, out_ch,
+                               training=True)
+    cand = O.deep_mel_forward(of, sb.features, 24, 4, out_ch, training=True)
+    loss_ref = O.clip_loss(est, cand)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) < LOSS_TOL
+    gscale = max(v.grad.double().norm().item() for v in list(om.values()) + list(of.values())
+                 if v.requires_grad and v.grad is not None)
+    for name, mod, ref in (("model", model, om), ("feature_model", fmodel, of)):
+        for k, p in mod.named_parameters():
+            assert close(p.grad, ref[k].grad, GRAD_TOL, gscale), (name, k, rel_l2(p.grad, ref[k].grad))
