@@ -42,6 +42,7 @@ CLIP_CONV = dict(depth=10, kernel_size=3, dilation_growth=2, dilation_period=5, 
                  subject_layers_dim="input", subject_dim=0)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak (opt-in --dtype bf16 mode only)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -110,8 +111,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--negatives", default=None, choices=["local", "node"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="MFMA operand type. f32 (default) is the parity-green headline; bf16 is the "
+                         "opt-in reduced-precision mode (fp32 accumulate, tolerance 1e-2) and is "
+                         "reported for information only")
     args = ap.parse_args()
 
+    hip_ops.set_compute_dtype(args.dtype)
     distrib.init()
     rank, world = distrib.rank(), distrib.world_size()
     if world != args.gpus:
@@ -166,7 +172,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: gwilliams2022-shaped MEG C={c['C']} T={c['T']}, "
                                f"F={c['F']} features, {c['S']} subjects, clip_conv SimpleConv "
                                f"({n_params} params) + ClipLoss + Adam",
@@ -174,8 +180,10 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": final_loss,
                    "step_tflops": seg_flops * B * world * args.steps / elapsed / 1e12},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
-                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "peak": PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
+                     "unit": "TFLOP/s",
+                     "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32"
+                                         else PEAK_BF16_MFMA_TFLOPS), "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
                      "traffic_source": traffic_src,
                      "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,

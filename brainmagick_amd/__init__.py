@@ -1,0 +1,2 @@
+"""MI355X-native SimpleConv + ClipLoss training hot path."""
+from .hip_ops import set_compute_dtype, get_compute_dtype  # noqa: F401

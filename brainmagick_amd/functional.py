@@ -214,7 +214,7 @@ class ChannelMergerFn(torch.autograd.Function):
         emb = H.fourier_emb(positions_u, D)
         seg = torch.arange(U + 1, dtype=torch.int32, device=meg.device)
         scores = H.gemm_nt(heads, emb, U, O, C, D, a_strides=(0, D), x_strides=(C * D, D), seg=seg,
-                           G=U).view(U, O, C)
+                           G=U, force_f32=True).view(U, O, C)
         weights = H.masked_softmax(scores, positions_u, ban_center, ban_radius)
         widx = layout_index.to(torch.int32)
         wp = H.pack_weights(weights, U, O, C, 1, O * C, C, 1, 0)

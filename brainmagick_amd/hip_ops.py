@@ -15,6 +15,23 @@ from ._lib import lib, check, BmHipError
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 BKC = 16
 
+# Compute mode of the MFMA contractions: "f32" (default, exact-fp32 MFMA, parity-green against the
+# fp32 reference) or "bf16" (opt-in: operands rounded to bf16 while staged into LDS, fp32 accumulate;
+# 16x the matrix rate, tolerance 1e-2).  Activations / parameters / gradients stay fp32 in HBM.
+import os as _os
+_compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", "f32")
+
+
+def set_compute_dtype(name: str):
+    global _compute_dtype
+    if name not in ("f32", "bf16"):
+        raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+    _compute_dtype = name
+
+
+def get_compute_dtype() -> str:
+    return _compute_dtype
+
 
 class KernelTimer:
     """Optional HIP-event timing of the MFMA kernels, on the stream they are launched on (the
@@ -84,6 +101,12 @@ def conv_mpad(M: int) -> int:
 def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, sm: int, sc: int,
                  sj: int, flip: bool = False, alpha: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, "pack_weights.src")
+    if _compute_dtype == "bf16":
+        n = lib().bm_packed_weight_elems_bf16(G, M, Cin, KS)
+        dst = torch.empty(n, device=src.device, dtype=torch.bfloat16)
+        check(lib().bm_pack_weights_bf16(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
+                                         _p(_opt(alpha, "alpha")), _stream()), "bm_pack_weights_bf16")
+        return dst
     n = lib().bm_packed_weight_elems(G, M, Cin, KS)
     dst = torch.empty(n, device=src.device, dtype=torch.float32)
     check(lib().bm_pack_weights(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
@@ -109,7 +132,8 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
             want_stats: bool = False):
     """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T]."""
     _req(x, "conv_nn.x")
-    _req(wpacked, "conv_nn.w")
+    bf16 = wpacked.dtype == torch.bfloat16          # packed by pack_weights in bf16 compute mode
+    _req(wpacked, "conv_nn.w", torch.bfloat16 if bf16 else torch.float32)
     B, Cin, T = x.shape
     y_pre = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_pre else None
     y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
@@ -120,15 +144,17 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))
+    fn = lib().bm_conv1d_nn_bf16 if bf16 else lib().bm_conv1d_nn
+
     def launch():
-        check(lib().bm_conv1d_nn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
-                                 _p(_opt(bias, "bias")), _p(_opt(scale, "scale")),
-                                 _p(_opt(shift, "shift")), _p(res), M * T, _p(y_pre), _p(y_out),
-                                 M * T, _p(stats), B, Cin, M, T, KS, dil, act, leak, _stream()),
-              "bm_conv1d_nn")
+        check(fn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
+                 _p(_opt(bias, "bias")), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")), _p(res),
+                 M * T, _p(y_pre), _p(y_out), M * T, _p(stats), B, Cin, M, T, KS, dil, act, leak,
+                 _stream()), "bm_conv1d_nn_bf16" if bf16 else "bm_conv1d_nn")
     if _timer is not None:
-        _timer.launch(f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>", 2.0 * B * T * M * Cin * KS,
-                      launch)
+        label = f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>" if bf16 else \
+            f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>"
+        _timer.launch(label, 2.0 * B * T * M * Cin * KS, launch)
     else:
         launch()
     return y_pre, y_out, stats
@@ -147,8 +173,12 @@ def group_by_index(idx: torch.Tensor, G: int):
 
 def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, KS: int = 1,
             dil: int = 1, a_strides=None, x_strides=None, order=None, seg=None, G: int = 1,
-            out: tp.Optional[torch.Tensor] = None, out_strides=None, nsplit: tp.Optional[int] = None):
+            out: tp.Optional[torch.Tensor] = None, out_strides=None, nsplit: tp.Optional[int] = None,
+            force_f32: bool = False):
     """out[g*sg + m*sm + c*sc + j*sj] = sum_{s in g} sum_t a[s][m][t] * x[s][c][t + shift_j].
+
+    In bf16 compute mode the weight-gradient contractions use bf16-rounded operands; callers whose
+    result feeds a softmax (merger logits, ClipLoss scores) pass ``force_f32``.
 
     a_strides / x_strides = (segment stride, row stride) in elements; defaults are contiguous
     [S][rows][T].  Default ``out`` is [G][M][Cn][KS] contiguous."""
@@ -172,13 +202,16 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = out
     else:
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
+    bf16 = _compute_dtype == "bf16" and not force_f32
+    fn = lib().bm_gemm_nt_bf16 if bf16 else lib().bm_gemm_nt
+
     def launch():
-        check(lib().bm_gemm_nt(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
-                               _p(_opt(order, "order", torch.int32)),
-                               _p(_opt(seg, "seg", torch.int32)), _p(part), S, G, M, Cn, T, KS, dil,
-                               nsplit, _stream()), "bm_gemm_nt")
+        check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
+                 _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)), _p(part), S,
+                 G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
     if _timer is not None:
-        _timer.launch(f"gemm_nt_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS, launch)
+        _timer.launch(f"gemm_nt{'_bf16' if bf16 else ''}_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS,
+                      launch)
     else:
         launch()
     if part is not out:

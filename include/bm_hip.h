@@ -58,6 +58,23 @@ int bm_conv1d_nn(const float* x, long x_bstride, const float* wpacked, const int
                  long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                  int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
 
+/* ---- OPT-IN bf16-operand / fp32-accumulate variant (conv_nn_bf16.hip): v_mfma_f32_32x32x16_bf16 ----
+ * Same contract as bm_conv1d_nn; x / bias / residual / outputs stay fp32, the MFMA operands are
+ * rounded to bf16 while staged into LDS.  Not the parity-green default (tolerance 1e-2). */
+int bm_conv_bf16_mt_for(int M);
+int bm_conv_bf16_mpad(int M);
+long bm_packed_weight_elems_bf16(int G, int M, int Cin, int KS);
+int bm_pack_weights_bf16(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
+                         long sc, long sj, int flip, const float* alpha_ptr, void* stream);
+int bm_conv1d_nn_bf16(const float* x, long x_bstride, const void* wpacked, const int* widx,
+                      const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                      long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
+                      int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
+
+int bm_gemm_nt_bf16(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
+                    long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
+                    int Cn, int T, int KS, int dil, int nsplit, void* stream);
+
 /* ---- time-contraction GEMM, fp32 MFMA, split-K (gemm_nt.hip) ----
  * part[g,split][m][c*KS+j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j-KS/2)*dil].
  * Replaces aten::convolution_backward (weight part), the weight-grad einsums of SubjectLayers /
