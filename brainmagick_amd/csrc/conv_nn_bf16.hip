@@ -12,8 +12,9 @@
 //   LDS x window    [8 groups][XW] x 16 B      -> tap j of output column n = slot n + j*dil
 // Staging: a thread loads the SAME time sample of 8 consecutive channels (8 coalesced dword loads),
 // converts and writes one 16-byte slot.  The K loop is software-pipelined exactly like the fp32
-// kernel: stage = (chunk, tap); the A slab of the next stage and 1/KS of the next chunk's x window
-// are in flight during the MFMAs and are written to the other LDS buffer afterwards.
+// kernel: stage = (chunk, tap); the A slab of the next stage is in flight during the MFMAs of a
+// stage, the whole x window of the next chunk is requested at the chunk's first stage and 1/KS of it
+// is converted and written to the other LDS buffer after each stage (flight time = up to KS stages).
 #include "conv_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
     typename UVecB<4 * AIT>::type areg;
-    typename FVecB<8 * IPS>::type xreg;
+    typename FVecB<8 * NIT>::type xreg;               // whole next-chunk window, in flight for KS stages
 
     // A slab of stage S_ (= chunk*KS + tap): KG runs of BM slots
 #define LOAD_A(S_)                                                                                \
@@ -99,19 +100,17 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
     }
     // x items: wavefront w stages channel groups 2w and 2w+1; item it in [0,6): group 2w + it/3,
     // columns lane + 64*(it%3).  Part PART_ of a chunk = items PART_, PART_+KS, ...
-#define LOAD_X(CHUNK_, PART_)                                                                     \
+#define LOAD_X(CHUNK_)                                                                            \
     {                                                                                             \
-        _Pragma("unroll") for (int u = 0; u < IPS; ++u) {                                         \
-            const int it = (PART_) + u * KS;                                                      \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                      \
             const int kg = 2 * wave + it / 3;                                                     \
             const int xx = lane + 64 * (it % 3);                                                  \
             const int t = n0 - halo + xx;                                                         \
             const int cbase = (CHUNK_) * BKC2 + kg * 8;                                           \
-            const bool tok = it < NIT && xx < XW && t >= 0 && t < a.T;                            \
-            _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                       \
-                const int c = cbase + r;                                                          \
-                xreg[8 * u + r] = (tok && c < a.Cin) ? xb[(long)c * a.T + t] : 0.f;               \
-            }                                                                                     \
+            const bool tok = xx < XW && t >= 0 && t < a.T;                                        \
+            const float* col = xb + (long)cbase * a.T + t;                                        \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r)                                         \
+                xreg[8 * it + r] = (tok && cbase + r < a.Cin) ? col[(long)r * a.T] : 0.f;         \
         }                                                                                         \
     }
 #define STORE_X(BUF_, PART_)                                                                      \
@@ -119,23 +118,24 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
         u32x4* dst = Xs + (BUF_) * KG * XW;                                                       \
         _Pragma("unroll") for (int u = 0; u < IPS; ++u) {                                         \
             const int it = (PART_) + u * KS;                                                      \
-            const int kg = 2 * wave + it / 3;                                                     \
-            const int xx = lane + 64 * (it % 3);                                                  \
-            if (it < NIT && xx < XW)                                                              \
-                dst[kg * XW + xx] = pack8_bf16(xreg[8 * u], xreg[8 * u + 1], xreg[8 * u + 2],     \
-                                               xreg[8 * u + 3], xreg[8 * u + 4], xreg[8 * u + 5], \
-                                               xreg[8 * u + 6], xreg[8 * u + 7]);                 \
+            if (it < NIT) {                                                                       \
+                const int kg = 2 * wave + it / 3;                                                 \
+                const int xx = lane + 64 * (it % 3);                                              \
+                if (xx < XW)                                                                      \
+                    dst[kg * XW + xx] = pack8_bf16(xreg[8 * it], xreg[8 * it + 1], xreg[8 * it + 2], \
+                                                   xreg[8 * it + 3], xreg[8 * it + 4],            \
+                                                   xreg[8 * it + 5], xreg[8 * it + 6],            \
+                                                   xreg[8 * it + 7]);                             \
+            }                                                                                     \
         }                                                                                         \
     }
 
     // prologue: stage 0 A slab and the whole window of chunk 0
     LOAD_A(0);
     STORE_A(0);
+    LOAD_X(0);
 #pragma unroll
-    for (int part = 0; part < KS; ++part) {
-        LOAD_X(0, part);
-        STORE_X(0, part);
-    }
+    for (int part = 0; part < KS; ++part) STORE_X(0, part);
     __syncthreads();
 
     const int nstage = a.nchunk * KS;
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
         for (int j = 0; j < KS; ++j, ++s) {
             const bool more_a = s + 1 < nstage;
             if (more_a) LOAD_A(s + 1);
-            if (more_x) LOAD_X(chunk + 1, j);
+            if (more_x && j == 0) LOAD_X(chunk + 1);   // whole window: in flight for the KS stages
             const u32x4* abuf = As + (s & 1) * KG * BM;
             const u32x4* xcol = xbuf + wave * 32 + nl + j * a.dil;
-#pragma unroll
-            for (int ks = 0; ks < KG / 2; ++ks) {
+#pragma unroll 1
+            for (int ks = 0; ks < KG / 2; ++ks) {      // not unrolled: keeps the operand fragments of ONE k-step live
                 const bf16x8 bv = __builtin_bit_cast(bf16x8, xcol[(2 * ks + h) * XW]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {

@@ -93,6 +93,10 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_bf16_kernel(GemmNTArg
             if ((OK_) && (T_) + 4 >= 0 && (T_) + 4 < a.T) v1 = *reinterpret_cast<const float4*>((ROW_) + (T_) + 4); \
             DST_[OFF_] = v0.x; DST_[OFF_ + 1] = v0.y; DST_[OFF_ + 2] = v0.z; DST_[OFF_ + 3] = v0.w; \
             DST_[OFF_ + 4] = v1.x; DST_[OFF_ + 5] = v1.y; DST_[OFF_ + 6] = v1.z; DST_[OFF_ + 7] = v1.w; \
+        } else if ((OK_) && (T_) >= 0 && (T_) + 8 <= a.T) {                                       \
+            /* interior run: one address, eight immediate-offset dword loads */                   \
+            const float* p8 = (ROW_) + (T_);                                                      \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) DST_[OFF_ + r] = p8[r];                 \
         } else {                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                       \
                 const int tt = (T_) + r;                                                          \
