@@ -72,11 +72,11 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    typename UVecB<4 * AIT>::type areg;
+    typename UVecB<4 * AIT>::type areg0, areg1;       // A slab of stage s lives in set s & 1, two stages in flight
     typename FVecB<8 * NIT>::type xreg;               // whole next-chunk window, in flight for KS stages
 
     // A slab of stage S_ (= chunk*KS + tap): KG runs of BM slots
-#define LOAD_A(S_)                                                                                \
+#define LOAD_A(AREG_, S_)                                                                              \
     {                                                                                             \
         const u32x4* wsrc = wg + (long)(S_) * KG * a.Mpad;                                        \
         _Pragma("unroll") for (int i = 0; i < AIT; ++i) {                                         \
@@ -84,16 +84,16 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
             e = e < KG * BM ? e : KG * BM - 1;                                                    \
             const int kg = e / BM, mm = e - kg * BM;                                              \
             const u32x4 v = wsrc[(long)kg * a.Mpad + mm];                                         \
-            areg[4 * i] = v[0]; areg[4 * i + 1] = v[1]; areg[4 * i + 2] = v[2]; areg[4 * i + 3] = v[3]; \
+            AREG_[4 * i] = v[0]; AREG_[4 * i + 1] = v[1]; AREG_[4 * i + 2] = v[2]; AREG_[4 * i + 3] = v[3]; \
         }                                                                                         \
     }
-#define STORE_A(BUF_)                                                                             \
+#define STORE_A(AREG_, BUF_)                                                                             \
     {                                                                                             \
         u32x4* dst = As + (BUF_) * KG * BM;                                                       \
         _Pragma("unroll") for (int i = 0; i < AIT; ++i) {                                         \
             const int e = tid + i * 256;                                                          \
             if (e < KG * BM) {                                                                    \
-                u32x4 v; v[0] = areg[4 * i]; v[1] = areg[4 * i + 1]; v[2] = areg[4 * i + 2]; v[3] = areg[4 * i + 3]; \
+                u32x4 v; v[0] = AREG_[4 * i]; v[1] = AREG_[4 * i + 1]; v[2] = AREG_[4 * i + 2]; v[3] = AREG_[4 * i + 3]; \
                 dst[e] = v;                                                                       \
             }                                                                                     \
         }                                                                                         \
@@ -130,40 +130,61 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
         }                                                                                         \
     }
 
-    // prologue: stage 0 A slab and the whole window of chunk 0
-    LOAD_A(0);
-    STORE_A(0);
+    // prologue: A slab of stage 0 -> LDS, A slab of stage 1 in flight (set 1), window of chunk 0
+    const int nstage = a.nchunk * KS;
+    LOAD_A(areg0, 0);
+    STORE_A(areg0, 0);
+    if (nstage > 1) LOAD_A(areg1, 1);
     LOAD_X(0);
 #pragma unroll
     for (int part = 0; part < KS; ++part) STORE_X(0, part);
     __syncthreads();
 
-    const int nstage = a.nchunk * KS;
-    int s = 0;
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        const u32x4* xbuf = Xs + (chunk & 1) * KG * XW;
-        const bool more_x = chunk + 1 < a.nchunk;
-#pragma unroll
-        for (int j = 0; j < KS; ++j, ++s) {
-            const bool more_a = s + 1 < nstage;
-            if (more_a) LOAD_A(s + 1);
-            if (more_x && j == 0) LOAD_X(chunk + 1);   // whole window: in flight for the KS stages
-            const u32x4* abuf = As + (s & 1) * KG * BM;
-            const u32x4* xcol = xbuf + wave * 32 + nl + j * a.dil;
-#pragma unroll 1
-            for (int ks = 0; ks < KG / 2; ++ks) {      // not unrolled: keeps the operand fragments of ONE k-step live
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, xcol[(2 * ks + h) * XW]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 av = __builtin_bit_cast(bf16x8, abuf[(2 * ks + h) * BM + mt * 32 + nl]);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mt], 0, 0, 0);
-                }
-            }
-            if (more_a) STORE_A((s + 1) & 1);
-            if (more_x) STORE_X((chunk + 1) & 1, j);
-            __syncthreads();
-        }
+    // One pipeline stage s = chunk*KS + tap.  A(s+2) is requested into the register set that held
+    // A(s) (already in LDS), A(s+1) -- requested one stage ago -- is written to the other LDS buffer
+    // after the MFMAs: two stages of flight time for the weight slabs.
+#define STAGE(CHUNK_, J_, AL_, AS_)                                                               \
+    {                                                                                             \
+        const int s_ = (CHUNK_) * KS + (J_);                                                      \
+        const bool more_x_ = (CHUNK_) + 1 < a.nchunk;                                             \
+        if (s_ + 2 < nstage) LOAD_A(AL_, s_ + 2);                                                 \
+        if ((J_) == 0 && more_x_) LOAD_X((CHUNK_) + 1);                                           \
+        const u32x4* abuf = As + (s_ & 1) * KG * BM;                                              \
+        const u32x4* xcol = Xs + ((CHUNK_) & 1) * KG * XW + wave * 32 + nl + (J_) * a.dil;        \
+        _Pragma("unroll 1") for (int ks = 0; ks < KG / 2; ++ks) {                                 \
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, xcol[(2 * ks + h) * XW]);                \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                   \
+                const bf16x8 av = __builtin_bit_cast(bf16x8, abuf[(2 * ks + h) * BM + mt * 32 + nl]); \
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mt], 0, 0, 0);      \
+            }                                                                                     \
+        }                                                                                         \
+        if (s_ + 1 < nstage) STORE_A(AS_, (s_ + 1) & 1);                                          \
+        if (more_x_) STORE_X(((CHUNK_) + 1) & 1, (J_));                                           \
+        __syncthreads();                                                                          \
     }
+    // the register-set roles alternate with the parity of s; KS is odd, so they flip every chunk:
+    // even chunks start with (load -> set 0, store <- set 1), odd chunks with the opposite.
+#define CHUNK_EVEN(C_)                                                                            \
+    {                                                                                             \
+        STAGE(C_, 0, areg0, areg1)                                                                \
+        if constexpr (KS >= 3) { STAGE(C_, 1, areg1, areg0) STAGE(C_, 2, areg0, areg1) }          \
+        if constexpr (KS >= 5) { STAGE(C_, 3, areg1, areg0) STAGE(C_, 4, areg0, areg1) }          \
+    }
+#define CHUNK_ODD(C_)                                                                             \
+    {                                                                                             \
+        STAGE(C_, 0, areg1, areg0)                                                                \
+        if constexpr (KS >= 3) { STAGE(C_, 1, areg0, areg1) STAGE(C_, 2, areg1, areg0) }          \
+        if constexpr (KS >= 5) { STAGE(C_, 3, areg0, areg1) STAGE(C_, 4, areg1, areg0) }          \
+    }
+    int chunk = 0;
+    for (; chunk + 1 < a.nchunk; chunk += 2) {
+        CHUNK_EVEN(chunk)
+        CHUNK_ODD(chunk + 1)
+    }
+    if (chunk < a.nchunk) CHUNK_EVEN(chunk)
+#undef STAGE
+#undef CHUNK_EVEN
+#undef CHUNK_ODD
 #undef LOAD_A
 #undef STORE_A
 #undef LOAD_X
