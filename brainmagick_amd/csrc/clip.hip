@@ -216,3 +216,78 @@ extern "C" int bm_row_axpy_sub(float* y, const float* x, const float* coef, int 
     hipLaunchKernelGGL(row_axpy_kernel, dim3(bx, rows), dim3(256), 0, (hipStream_t)stream, y, x, coef, K, K4);
     return bm_check_launch("row_axpy_sub");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Word-level retrieval (bm/wer.py:91-116), batched.  Row softmax of a score matrix, per-row dot
+// products est_i . out_i (the segment's own target replaces the last negative, wer.py:93-94), and the
+// aggregation of candidate probabilities per vocabulary word (wer.py:100-103) as a deterministic
+// segmented sum over columns pre-sorted by word.
+// ------------------------------------------------------------------------------------------------
+__global__ void row_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * cols;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xr[c]);
+    mx = bm_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += expf(xr[c] - mx);
+    s = bm_wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < cols; c += 64) y[(long)row * cols + c] = expf(xr[c] - mx) * inv;
+}
+
+extern "C" int bm_row_softmax(const float* x, float* y, int rows, int cols, void* stream) {
+    BM_REQUIRE(x && y, "row_softmax: null pointer");
+    if (rows == 0) return BM_OK;
+    hipLaunchKernelGGL(row_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols);
+    return bm_check_launch("row_softmax");
+}
+
+// out[r] = scale[r] * <a[r], b[r]>   (rows of length K)
+__global__ __launch_bounds__(256) void rowwise_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ scale, float* __restrict__ out,
+                                                          long K) {
+    __shared__ double sh[4];
+    const float* ar = a + (long)blockIdx.x * K;
+    const float* br = b + (long)blockIdx.x * K;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < K; i += blockDim.x) s += ar[i] * br[i];
+    double d = bm_wave_sum_d((double)s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]) * (scale ? scale[blockIdx.x] : 1.f);
+}
+
+extern "C" int bm_rowwise_dot(const float* a, const float* b, const float* scale, float* out, int rows, long K,
+                              void* stream) {
+    BM_REQUIRE(a && b && out, "rowwise_dot: null pointer");
+    if (rows == 0) return BM_OK;
+    hipLaunchKernelGGL(rowwise_dot_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, b, scale, out, K);
+    return bm_check_launch("rowwise_dot");
+}
+
+// pv[r][v] = sum_{k in [seg[v], seg[v+1])} p[r][order[k]]   (columns grouped by vocabulary word)
+__global__ void segment_sum_cols_kernel(const float* __restrict__ p, const int* __restrict__ order,
+                                        const int* __restrict__ seg, float* __restrict__ pv, int rows,
+                                        int cols, int V) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = p + (long)row * cols;
+    for (int v = lane; v < V; v += 64) {
+        float s = 0.f;
+        for (int k = seg[v]; k < seg[v + 1]; ++k) s += pr[order[k]];
+        pv[(long)row * V + v] = s;
+    }
+}
+
+extern "C" int bm_segment_sum_cols(const float* p, const int* order, const int* seg, float* pv, int rows,
+                                   int cols, int V, void* stream) {
+    BM_REQUIRE(p && order && seg && pv, "segment_sum_cols: null pointer");
+    if (rows == 0 || V == 0) return BM_OK;
+    hipLaunchKernelGGL(segment_sum_cols_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, order,
+                       seg, pv, rows, cols, V);
+    return bm_check_launch("segment_sum_cols");
+}

@@ -169,7 +169,7 @@ extern "C" int bm_affine_act_res(const float* y, const float* scale, const float
 // backward of  out = act(bn(y)) [+ res]
 //   dz = dout * act'(z),  z = y*scale + shift
 //   train BN:  dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat)),  dgamma = sum dz*xhat, dbeta = sum dz
-//   eval BN:   dy = scale * dz ;  no BN:  dy = dz
+//   eval BN:   dy = scale * dz (dgamma / dbeta as in train mode, from the running statistics' xhat) ;  no BN:  dy = dz
 // Pass 1 (bn_bwd_reduce): per-(channel, split) partial sums.  Pass 2 (bn_bwd_apply): dy + sum(dy).
 // ------------------------------------------------------------------------------------------------
 #define NSPLIT_MAX 32
@@ -222,15 +222,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float sc = scale ? scale[c] : 1.f, shf = scale ? shift[c] : 0.f;
     const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
     float k1 = 0.f, k2 = 0.f;
-    if (bn_train) {
+    if (scale && (bn_train || dgamma || dbeta)) {   // BatchNorm: the reduce pass ran (train, or eval with affine grads)
         double sdz = 0, sdzx = 0;
         for (int k = 0; k < nsplit; ++k) {
             sdz += partial[((long)c * nsplit + k) * 2 + 0];
             sdzx += partial[((long)c * nsplit + k) * 2 + 1];
         }
-        const double n = (double)B * T;
-        k1 = (float)(sdz / n);
-        k2 = (float)(sdzx / n);
+        if (bn_train) {
+            const double n = (double)B * T;
+            k1 = (float)(sdz / n);
+            k2 = (float)(sdzx / n);
+        }
         if (split == 0 && threadIdx.x == 0) {
             if (dgamma) dgamma[c] = (float)sdzx;
             if (dbeta) dbeta[c] = (float)sdz;
@@ -293,14 +295,15 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     double* dy_partial = partial + (long)2 * C * nsplit;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(C, nsplit);
+    const bool reduce = bn_train || (scale && (dgamma || dbeta));
     if (T % 4 == 0) {
-        if (bn_train)
+        if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak);
     } else {
-        if (bn_train)
+        if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,

@@ -128,9 +128,6 @@ class ConvBNActFn(torch.autograd.Function):
         M, Cin, _ = weight.shape
         dy, dgamma, dbeta, dbias = H.act_bn_bwd(dout, pre, scale, shift, mean, invstd, training, act,
                                                 leak, want_affine_grads=True, want_dbias=has_bias)
-        if not training:
-            # eval-mode BN: gamma/beta grads from the normalised input
-            dgamma = dbeta = None
         dx = None
         if ctx.needs_input_grad[0]:
             _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight), Cin, KS, dil,

@@ -433,6 +433,34 @@ def center_scale(x: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
     return out, maxabs
 
 
+def row_softmax(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "row_softmax.x")
+    y = torch.empty_like(x)
+    check(lib().bm_row_softmax(_p(x), _p(y), x.shape[0], x.shape[1], _stream()), "bm_row_softmax")
+    return y
+
+
+def rowwise_dot(a: torch.Tensor, b: torch.Tensor, scale=None) -> torch.Tensor:
+    _req(a, "rowwise_dot.a")
+    _req(b, "rowwise_dot.b")
+    rows = a.shape[0]
+    out = torch.empty(rows, device=a.device, dtype=torch.float32)
+    check(lib().bm_rowwise_dot(_p(a), _p(b), _p(_opt(scale, "scale")), _p(out), rows,
+                               a.numel() // max(rows, 1), _stream()), "bm_rowwise_dot")
+    return out
+
+
+def segment_sum_cols(p: torch.Tensor, order: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
+    _req(p, "segment_sum_cols.p")
+    rows, cols = p.shape
+    V = seg.numel() - 1
+    pv = torch.empty(rows, V, device=p.device, dtype=torch.float32)
+    check(lib().bm_segment_sum_cols(_p(p), _p(_req(order, "order", torch.int32)),
+                                    _p(_req(seg, "seg", torch.int32)), _p(pv), rows, cols, V, _stream()),
+          "bm_segment_sum_cols")
+    return pv
+
+
 def topk_rows(x: torch.Tensor, k: int, col_labels=None, row_labels=None):
     """x [N, V] -> (idx [N, k] int32, values [N, k], hits [N] int32 | None)."""
     _req(x, "topk_rows.x")

@@ -139,6 +139,14 @@ int bm_row_axpy_sub(float* y, const float* x, const float* coef, int rows, long 
 int bm_topk_rows(const float* x, int rows, int cols, int k, int* idx_out, float* val_out,
                  const long* col_labels, const long* row_labels, int* hit_out, void* stream);
 
+/* Word-level retrieval, batched (bm/wer.py:91-116): row softmax, per-row dot products (own target
+ * replaces the last negative), per-vocabulary-word sums over columns pre-sorted by word. */
+int bm_row_softmax(const float* x, float* y, int rows, int cols, void* stream);
+int bm_rowwise_dot(const float* a, const float* b, const float* scale, float* out, int rows, long K,
+                   void* stream);
+int bm_segment_sum_cols(const float* p, const int* order, const int* seg, float* pv, int rows, int cols,
+                        int V, void* stream);
+
 /* ---- fused Adam on the flat bucket (adam.hip)  torch.optim.Adam @ bm/train.py:118-119 ---- */
 int bm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
                  double lr, double beta1, double beta2, double eps, double grad_scale, void* stream);

@@ -335,6 +335,29 @@ def topk_accuracy(probs: torch.Tensor, labels: torch.Tensor, row_labels: torch.T
     return hit.float().mean().item()
 
 
+def get_wer_loop(estimates, outputs, word_hashes, kept, topx=10):
+    """bm/wer.py:71-120, the per-segment loop exactly as written (``kept`` = the indices drawn by the
+    randperm at :72-73).  Returns {'wer', 'wer_vocab'}."""
+    negatives = outputs[kept].clone()
+    negative_hashes = word_hashes[kept].clone()
+    correct = 0.
+    correct_vocab = 0.
+    for estimate, word_hash, output in zip(estimates, word_hashes, outputs):
+        negatives[-1] = output
+        negative_hashes[-1] = word_hash
+        probas = clip_probabilities(estimate[None], negatives)[0]
+        negative_hashes_vocab, indices = torch.unique(negative_hashes, return_inverse=True)
+        probas_vocab = torch.zeros(len(negative_hashes_vocab), dtype=probas.dtype)
+        probas_vocab.scatter_add_(0, indices, probas)
+        _, bests = probas.topk(min(topx, len(probas)))
+        _, bests_vocab = probas_vocab.topk(min(topx, len(probas_vocab)))
+        correct += (negative_hashes[bests] == word_hash).any().item()
+        correct_vocab += (negative_hashes_vocab[bests_vocab] == word_hash).any().item()
+    correct /= len(estimates)
+    correct_vocab /= len(estimates)
+    return {'wer': 1 - correct, 'wer_vocab': 1 - correct_vocab}
+
+
 # ----------------------------------------------------------------------------------------------
 # ScaleReject front end
 # ----------------------------------------------------------------------------------------------

@@ -180,17 +180,20 @@ def test_batchnorm_act_residual(H, T, act):
 
     # eval mode: running statistics
     y2 = y.detach().clone().requires_grad_(True)
-    out_ref = fn(F.batch_norm(y2, rm, rv, gamma.detach(), beta.detach(), training=False, eps=1e-5))
+    g2 = gamma.detach().clone().requires_grad_(True)
+    b2 = beta.detach().clone().requires_grad_(True)
+    out_ref = fn(F.batch_norm(y2, rm, rv, g2, b2, training=False, eps=1e-5))
     out_ref.backward(dout)
     mean, invstd, scale, shift = H.bn_eval_affine(gamma.detach().float().cuda(),
                                                   beta.detach().float().cuda(), rm.float().cuda(),
                                                   rv.float().cuda(), 1e-5)
     out = H.affine_act_res(yf.cuda(), scale, shift, None, code, 0.1)
     assert rel_l2(out, out_ref) < FWD_TOL
-    dy, _, _, dbias = H.act_bn_bwd(dout.float().cuda(), yf.cuda(), scale, shift, mean, invstd, False,
-                                   code, 0.1)
+    dy, dg_e, db_e, dbias = H.act_bn_bwd(dout.float().cuda(), yf.cuda(), scale, shift, mean, invstd,
+                                         False, code, 0.1, want_affine_grads=True)
     assert rel_l2(dy, y2.grad) < GRAD_TOL
     assert rel_l2(dbias, y2.grad.sum((0, 2))) < GRAD_TOL
+    assert rel_l2(dg_e, g2.grad) < GRAD_TOL and rel_l2(db_e, b2.grad) < GRAD_TOL
     # no BN at all
     y3 = y.detach().clone().requires_grad_(True)
     fn(y3).backward(dout)
@@ -383,3 +386,24 @@ def test_clip_loss_candidate_gradients(B, Bc):
     (loss * 1.7).backward()
     assert rel_l2(eg.grad, est.grad) < GRAD_TOL
     assert rel_l2(cg.grad, cand.grad) < GRAD_TOL
+
+
+@pytest.mark.parametrize("n_neg", [None, 40])
+def test_word_level_wer_batched(H, n_neg):
+    """retrieval.get_wer (one GEMM + row kernels) vs the reference's per-segment loop (bm/wer.py:91-120)."""
+    from brainmagick_amd import retrieval
+    from brainmagick_amd.losses import ClipLoss
+    g = _gen(31)
+    n, Fd, T = 60, 5, 24
+    outputs = torch.randn(n, Fd, T, generator=g)
+    estimates = 0.12 * outputs + torch.randn(n, Fd, T, generator=g)
+    word_hashes = torch.randint(1, 13, (n,), generator=g).int()
+    gen = torch.Generator().manual_seed(5)
+    kept = torch.randperm(n, generator=gen)[:n_neg] if n_neg else torch.arange(n)
+    ref = O.get_wer_loop(estimates, outputs, word_hashes, kept, topx=3)
+    gen = torch.Generator().manual_seed(5)
+    got = retrieval.get_wer(ClipLoss().cuda(), estimates, outputs, word_hashes, n_negatives=n_neg,
+                            topx=3, generator=gen, batch_size=16)
+    assert got["wer"] == pytest.approx(ref["wer"], abs=1e-9)
+    assert got["wer_vocab"] == pytest.approx(ref["wer_vocab"], abs=1e-9)
+    assert 0 < ref["wer"] < 1
