@@ -403,3 +403,81 @@ def test_deep_mel_feature_model_step():
     for name, mod, ref in (("model", model, om), ("feature_model", fmodel, of)):
         for k, p in mod.named_parameters():
             assert close(p.grad, ref[k].grad, GRAD_TOL, gscale), (name, k, rel_l2(p.grad, ref[k].grad))
+
+
+def _small_model(C=20, Fd=10, S=3, hidden=32, seed=3, **over):
+    from brainmagick_amd.models import SimpleConv
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=32, merger_channels=16, initial_linear=16)
+    cfg.update(over)
+    torch.manual_seed(seed)
+    return SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S,
+                      **cfg), cfg
+
+
+@pytest.mark.parametrize("B,T", [(1, 360), (2, 24), (3, 7), (5, 129)])
+def test_edge_shapes_against_oracle(B, T):
+    """Single-segment batches (BatchNorm over T only), windows shorter than the 16-sample dilation
+    halo / one MFMA k-step, and a tile-boundary length."""
+    from brainmagick_amd.solver import Solver
+    model, cfg = _small_model()
+    sb = synthetic.make_batch(B, 20, T, 10, 3, seed=T)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, 32, 10)
+    ban = torch.tensor([0.9, 0.9])
+    model.merger.ban_center_override = ban
+    solver = Solver(model)
+    loss_ref, est_ref, grads_ref = oracle.loss_and_grads(sb.meg, sb.positions(), sb.subject_index,
+                                                         sb.features, True, ban)
+    loss = solver.train_step(sb)
+    assert abs(float(loss) - float(loss_ref)) < LOSS_TOL
+    gscale = max(v.double().norm().item() for v in grads_ref.values())
+    if B * T > 64:      # with a handful of samples per BatchNorm channel the problem is ill-conditioned
+        for k, p in model.named_parameters():
+            assert close(p.grad, grads_ref[k], 5 * GRAD_TOL, gscale), (k, rel_l2(p.grad, grads_ref[k]))
+
+
+def test_empty_batch_and_rejected_batch():
+    """bm/solver.py:255-256: a batch whose segments were all rejected yields four Nones."""
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
+    model, _ = _small_model()
+    sb = synthetic.make_batch(4, 20, 48, 10, 3, seed=1)
+    sb.meg = sb.meg * 1e4                       # every segment exceeds the rejection limit
+    sr = ScaleReject(DeviceBatchScaler(torch.zeros(1, 20), torch.ones(1, 20)), limit=20, clip=False)
+    solver = Solver(model, scale_reject=sr)
+    assert solver._process_batch(sb) == (None, None, None, None)
+    assert sr.rejection_rate == 1.0
+
+
+def test_all_sensors_banned_is_nan_like_reference():
+    """a sensor-dropout disc that covers every valid sensor gives an all -inf softmax row
+    -> NaN in the reference; replicated, not 'fixed'."""
+    model, cfg = _small_model(merger_dropout=5.0)        # radius covers the whole unit square
+    sb = synthetic.make_batch(2, 20, 48, 10, 3, seed=2)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, 32, 10)
+    ban = torch.tensor([0.5, 0.5])
+    est_ref = oracle.forward(sb.meg, sb.positions(), sb.subject_index, training=True, ban_center=ban)
+    model = model.cuda().train()
+    model.merger.ban_center_override = ban
+    sbg = sb.to("cuda")
+    est = model({"meg": sbg.meg}, sbg)
+    assert torch.isnan(est_ref).all() and torch.isnan(est).all()
+
+
+def test_target_offset_matches_rolled_candidates():
+    """ClipLoss(target_offset=k) == reference ClipLoss on candidates rolled so that the targets come
+    first (the whole-node negatives layout of a data-parallel rank)."""
+    from brainmagick_amd.losses import ClipLoss
+    g = torch.Generator().manual_seed(9)
+    est = torch.randn(4, 6, 30, generator=g)
+    cand = torch.randn(12, 6, 30, generator=g)
+    mask = torch.ones(4, 1, 30, dtype=torch.bool, device="cuda")
+    for off in (0, 4, 8):
+        e = est.cuda().requires_grad_(True)
+        loss = ClipLoss().cuda()(e, cand.cuda(), mask, target_offset=off)
+        loss.backward()
+        er = est.double().requires_grad_(True)
+        ref = O.clip_loss(er, torch.roll(cand.double(), -off, 0))
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 1e-5
+        assert rel_l2(e.grad, er.grad) < GRAD_TOL
