@@ -12,7 +12,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 HEADER = ROOT.parent / "include" / "bm_hip.h"
-LIB_PATH = ROOT / "libbmhip.so"
+LIB_PATH = Path(os.environ["BM_HIP_LIB"]) if os.environ.get("BM_HIP_LIB") else ROOT / "libbmhip.so"
 CSRC = ROOT / "csrc"
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,

@@ -17,6 +17,12 @@
 // is converted and written to the other LDS buffer after each stage (flight time = up to KS stages).
 #include "conv_common.h"
 
+// Measurement-only knob: issue every MFMA BM_MFMA_REP times (results are garbage for REP > 1); used
+// to price the matrix-pipe load of multi-pass bf16 emulation schemes.  Always 1 in the shipped build.
+#ifndef BM_MFMA_REP
+#define BM_MFMA_REP 1
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -155,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
             const bf16x8 bv = __builtin_bit_cast(bf16x8, xcol[(2 * ks + h) * XW]);                \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                   \
                 const bf16x8 av = __builtin_bit_cast(bf16x8, abuf[(2 * ks + h) * BM + mt * 32 + nl]); \
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mt], 0, 0, 0);      \
+                _Pragma("unroll") for (int rep_ = 0; rep_ < BM_MFMA_REP; ++rep_)                  \
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mt], 0, 0, 0);  \
             }                                                                                     \
         }                                                                                         \
         if (s_ + 1 < nstage) STORE_A(AS_, (s_ + 1) & 1);                                          \

@@ -15,17 +15,19 @@ from ._lib import lib, check, BmHipError
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 BKC = 16
 
-# Compute mode of the MFMA contractions: "f32" (default, exact-fp32 MFMA, parity-green against the
-# fp32 reference) or "bf16" (opt-in: operands rounded to bf16 while staged into LDS, fp32 accumulate;
-# 16x the matrix rate, tolerance 1e-2).  Activations / parameters / gradients stay fp32 in HBM.
+# Compute mode of the MFMA contractions.  Activations / parameters / gradients stay fp32 in HBM.
+#   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
+#   "f32x3" fp32-ACCURATE emulation on the bf16 matrix cores: both operands split exactly into three
+#           bf16 planes, six partial products per block, fp32 accumulate (error vs fp64 <= exact fp32's);
+#   "bf16"  opt-in reduced precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
 _compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", "f32")
 
 
 def set_compute_dtype(name: str):
     global _compute_dtype
-    if name not in ("f32", "bf16"):
-        raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+    if name not in ("f32", "bf16", "f32x3"):
+        raise ValueError(f"compute dtype must be 'f32', 'f32x3' or 'bf16', got {name!r}")
     _compute_dtype = name
 
 
@@ -101,11 +103,14 @@ def conv_mpad(M: int) -> int:
 def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, sm: int, sc: int,
                  sj: int, flip: bool = False, alpha: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, "pack_weights.src")
-    if _compute_dtype == "bf16":
-        n = lib().bm_packed_weight_elems_bf16(G, M, Cin, KS)
+    if _compute_dtype in ("bf16", "f32x3"):
+        x3 = _compute_dtype == "f32x3"
+        n = (lib().bm_packed_weight_elems_x3 if x3 else lib().bm_packed_weight_elems_bf16)(G, M, Cin, KS)
         dst = torch.empty(n, device=src.device, dtype=torch.bfloat16)
-        check(lib().bm_pack_weights_bf16(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
-                                         _p(_opt(alpha, "alpha")), _stream()), "bm_pack_weights_bf16")
+        fn = lib().bm_pack_weights_x3 if x3 else lib().bm_pack_weights_bf16
+        check(fn(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip), _p(_opt(alpha, "alpha")),
+                 _stream()), "bm_pack_weights_x3" if x3 else "bm_pack_weights_bf16")
+        dst._bm_mode = _compute_dtype            # tells conv_nn which kernel family packed it
         return dst
     n = lib().bm_packed_weight_elems(G, M, Cin, KS)
     dst = torch.empty(n, device=src.device, dtype=torch.float32)
@@ -132,7 +137,8 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
             want_stats: bool = False):
     """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T]."""
     _req(x, "conv_nn.x")
-    bf16 = wpacked.dtype == torch.bfloat16          # packed by pack_weights in bf16 compute mode
+    mode = getattr(wpacked, "_bm_mode", "f32")      # set by pack_weights
+    bf16 = mode != "f32"
     _req(wpacked, "conv_nn.w", torch.bfloat16 if bf16 else torch.float32)
     B, Cin, T = x.shape
     y_pre = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_pre else None
@@ -144,16 +150,18 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))
-    fn = lib().bm_conv1d_nn_bf16 if bf16 else lib().bm_conv1d_nn
+    fn = {"f32": lib().bm_conv1d_nn, "bf16": lib().bm_conv1d_nn_bf16,
+          "f32x3": lib().bm_conv1d_nn_x3}[mode]
 
     def launch():
         check(fn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
                  _p(_opt(bias, "bias")), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")), _p(res),
                  M * T, _p(y_pre), _p(y_out), M * T, _p(stats), B, Cin, M, T, KS, dil, act, leak,
-                 _stream()), "bm_conv1d_nn_bf16" if bf16 else "bm_conv1d_nn")
+                 _stream()), f"bm_conv1d_nn[{mode}]")
     if _timer is not None:
-        label = f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>" if bf16 else \
-            f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>"
+        label = {"f32": f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>",
+                 "bf16": f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>",
+                 "f32x3": f"conv_nn_x3_kernel<{lib().bm_conv_bf16_mt_for(M)}>"}[mode]
         _timer.launch(label, 2.0 * B * T * M * Cin * KS, launch)
     else:
         launch()
@@ -202,16 +210,16 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = out
     else:
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
-    bf16 = _compute_dtype == "bf16" and not force_f32
-    fn = lib().bm_gemm_nt_bf16 if bf16 else lib().bm_gemm_nt
+    mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
+    fn = {"f32": lib().bm_gemm_nt, "bf16": lib().bm_gemm_nt_bf16, "f32x3": lib().bm_gemm_nt_x3}[mode]
 
     def launch():
         check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
                  _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)), _p(part), S,
                  G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
     if _timer is not None:
-        _timer.launch(f"gemm_nt{'_bf16' if bf16 else ''}_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS,
-                      launch)
+        suffix = {"f32": "", "bf16": "_bf16", "f32x3": "_x3"}[mode]
+        _timer.launch(f"gemm_nt{suffix}_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS, launch)
     else:
         launch()
     if part is not out:
@@ -227,9 +235,10 @@ def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
     if nsplit is None:
         nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, 1, S, T, 1)
     part = torch.empty(nsplit, M, Cn, device=a.device, dtype=torch.float32)
-    check(lib().bm_gemm_nt(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
-                           None, None, _p(part), S, 1, M, Cn, T, 1, 1, nsplit, _stream()),
-          "bm_gemm_nt")
+    # scores feed a softmax: exact fp32 or the fp32-accurate x3 path, never plain bf16
+    fn = lib().bm_gemm_nt_x3 if _compute_dtype == "f32x3" else lib().bm_gemm_nt
+    check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1], None, None, _p(part),
+             S, 1, M, Cn, T, 1, 1, nsplit, _stream()), "bm_gemm_nt")
     return part
 
 

@@ -71,6 +71,19 @@ int bm_conv1d_nn_bf16(const float* x, long x_bstride, const void* wpacked, const
                       long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                       int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
 
+/* ---- fp32-ACCURATE contraction on the bf16 matrix cores: exact 3-way bf16 split of both operands,
+ * six partial products per MFMA block, fp32 accumulate (conv_nn_x3.hip / gemm_nt_x3.hip).  Same
+ * contracts as bm_conv1d_nn / bm_gemm_nt; compute mode "f32x3". */
+long bm_packed_weight_elems_x3(int G, int M, int Cin, int KS);
+int bm_pack_weights_x3(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
+                       long sc, long sj, int flip, const float* alpha_ptr, void* stream);
+int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpacked, const int* widx,
+                    const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                    long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
+                    int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
+int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
+                  long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
+                  int Cn, int T, int KS, int dil, int nsplit, void* stream);
 int bm_gemm_nt_bf16(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                     long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                     int Cn, int T, int KS, int dil, int nsplit, void* stream);
