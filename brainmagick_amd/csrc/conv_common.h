@@ -22,11 +22,12 @@ struct ConvNNArgs {
 // wavefront w owns columns [32w, 32w+32)): bias, optional pre-activation store, optional per-tile
 // BatchNorm partial statistics, optional per-channel affine, activation, residual.
 // C/D layout of the 32x32 MFMA (dtype independent): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// `tid` is the thread index inside the 4-wavefront group that owns the tile (a workgroup may hold
+// two such groups, one per segment); `smem` is that group's reduction scratch.
 template <int MT>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvNNArgs& a, f32x16 (&acc)[MT], float* smem,
-                                                   int b, int ntile, int m0, int n0) {
+                                                   int b, int ntile, int m0, int n0, int tid) {
     constexpr int BM = 32 * MT;
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nl = lane & 31;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 3) void conv_nn_kernel(ConvNNArgs a) {
 #undef BM_LOAD_X
 #undef BM_STORE_X
 
-    conv_tile_epilogue<MT>(a, acc, smem, b, ntile, m0, n0);
+    conv_tile_epilogue<MT>(a, acc, smem, b, ntile, m0, n0, tid);
 }
 
 template <int MT, bool VEC>

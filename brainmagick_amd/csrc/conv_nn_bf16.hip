@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_nn_bf16_kernel(ConvNNArgs a) {
 #undef STORE_A
 #undef LOAD_X
 #undef STORE_X
-    conv_tile_epilogue<MT>(a, acc, smem, b, ntile, m0, n0);
+    conv_tile_epilogue<MT>(a, acc, smem, b, ntile, m0, n0, tid);
 }
 
 template <int MT, int KS>

@@ -5,8 +5,9 @@
 //
 //   part[g, split][m][c*KS + j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j - KS/2)*dil]
 //
-// LDS: rows of 32 samples = 4 slots of 16 bytes + 1 pad slot (5-slot pitch: conflict-free row-per-lane
-// ds_read_b128), three planes per operand, one pre-shifted copy of the X tile per tap (as in
+// LDS: rows of 32 samples = 4 slots of 16 bytes, slot index XOR-swizzled with bits 2-3 of the row so that
+// both the row-per-lane ds_read_b128 of the MFMA operands and the 8-lane ds_write_b128 groups of the
+// staging pass are bank-conflict free (a +1 pad slot made the writes 2-way); three planes per operand, one pre-shifted copy of the X tile per tap (as in
 // gemm_nt_bf16.hip).  Software pipeline, split-K, grouping and XCD mapping as in gemm_nt.hip.
 #include "bm_common.h"
 
@@ -14,8 +15,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define BKT2 32
-#define SLOTS 5          // 4 data slots + 1 pad per row
+#define SLOTS 4          // 4 data slots per row, XOR-swizzled: slot (row, q) lives at row*4 + (q ^ ((row >> 2) & 3))
 #define DSL 4            // data slots per row
+#define SWZ(ROW_, Q_) ((ROW_) * SLOTS + ((Q_) ^ (((ROW_) >> 2) & 3)))
 
 struct GemmNTArgsX {
     const float* a; long a_sstride; long a_rstride;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
             _Pragma("unroll") for (int r = 0; r < 8; ++r) f[r] = areg[8 * i + r];                 \
             u32x4 hi, mid, lo;                                                                    \
             split8x(f, hi, mid, lo);                                                              \
-            const int slot = (e >> 2) * SLOTS + (e & 3);                                          \
+            const int slot = SWZ(e >> 2, e & 3);                                                  \
             As[slot] = hi; As[BM * SLOTS + slot] = mid; As[2 * BM * SLOTS + slot] = lo;           \
         }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < XIT; ++i) {                                         \
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
                 _Pragma("unroll") for (int r = 0; r < 8; ++r) f[r] = xreg[8 * i + r];             \
                 u32x4 hi, mid, lo;                                                                \
                 split8x(f, hi, mid, lo);                                                          \
-                const int slot = (j * BC + (rem >> 2)) * SLOTS + (rem & 3);                       \
+                const int slot = j * BC * SLOTS + SWZ(rem >> 2, rem & 3);                         \
                 Xs[slot] = hi; Xs[KS * BC * SLOTS + slot] = mid; Xs[2 * KS * BC * SLOTS + slot] = lo; \
             }                                                                                     \
         }                                                                                         \
@@ -171,23 +173,27 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
     for (long q = q_begin; q < q_end; ++q) {
         const bool more = q + 1 < q_end;
         if (more) NT_LOAD(q + 1);
-        const u32x4* ap = As + (wm * MT * 32 + nl) * SLOTS + h;
-        const u32x4* xp = Xs + (wc * NT * 32 + nl) * SLOTS + h;
+        // row-per-lane operand reads; rows of the 32-row MFMA blocks start at multiples of 32, so the
+        // swizzle term only depends on the lane's row-in-block nl
+        const u32x4* ap = As + (wm * MT * 32 + nl) * SLOTS;
+        const u32x4* xp = Xs + (wc * NT * 32 + nl) * SLOTS;
+        const int sw = (nl >> 2) & 3;
         constexpr int APL = BM * SLOTS, XPL = KS * BC * SLOTS;      // plane strides
 #pragma unroll
         for (int kk = 0; kk < BKT2 / 16; ++kk) {
             bf16x8 ah[MT], am[MT], al[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                ah[i] = __builtin_bit_cast(bf16x8, ap[i * 32 * SLOTS + 2 * kk]);
-                am[i] = __builtin_bit_cast(bf16x8, ap[APL + i * 32 * SLOTS + 2 * kk]);
-                al[i] = __builtin_bit_cast(bf16x8, ap[2 * APL + i * 32 * SLOTS + 2 * kk]);
+                const int q = (2 * kk + h) ^ sw;
+                ah[i] = __builtin_bit_cast(bf16x8, ap[i * 32 * SLOTS + q]);
+                am[i] = __builtin_bit_cast(bf16x8, ap[APL + i * 32 * SLOTS + q]);
+                al[i] = __builtin_bit_cast(bf16x8, ap[2 * APL + i * 32 * SLOTS + q]);
             }
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
-                    const int o = (j * BC + k * 32) * SLOTS + 2 * kk;
+                    const int o = (j * BC + k * 32) * SLOTS + ((2 * kk + h) ^ sw);
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, xp[o]);
                     const bf16x8 bm = __builtin_bit_cast(bf16x8, xp[XPL + o]);
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, xp[2 * XPL + o]);

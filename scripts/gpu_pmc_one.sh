@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_one/p$i -o o -- python $R/scripts/probe_one.py bf16 > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_one/p$i -o o -- python $R/scripts/probe_one.py ${BM_PROBE_MODE:-bf16} > /dev/null 2>&1
 done
 cd $R
 python - <<'PY'
