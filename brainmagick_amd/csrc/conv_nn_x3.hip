@@ -6,7 +6,7 @@
 // (the three dropped ones are <= 2^-26 |a*b|), each an exact bf16 x bf16 product accumulated in fp32 by
 // v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs cost 6/16 of one exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
 // for the same 32x32x16 block, and the result is fp32-class: measured rel-L2 vs fp64 1.4e-7 against
-// 3.4e-7 for a plain fp32 FMA chain (tests/test_x3_gpu.py).  This is the compute mode "f32x3"
+// 3.4e-7 for a plain fp32 FMA chain (tests/test_exact_f32_gpu.py::test_x3_error_is_fp32_class).  This is the compute mode "f32x3"
 // (brainmagick_amd.set_compute_dtype("f32x3")); activations, parameters, gradients and every
 // elementwise kernel stay fp32.
 //

@@ -16,12 +16,15 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 BKC = 16
 
 # Compute mode of the MFMA contractions.  Activations / parameters / gradients stay fp32 in HBM.
+#   "f32x3" (default) fp32-ACCURATE contraction on the bf16 matrix cores: both fp32 operands are split
+#           EXACTLY into three bf16 planes, six partial products per block, fp32 accumulate; measured
+#           error vs fp64 <= the exact-fp32 MFMA path's, held to the same parity tolerances;
 #   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
-#   "f32x3" fp32-ACCURATE emulation on the bf16 matrix cores: both operands split exactly into three
-#           bf16 planes, six partial products per block, fp32 accumulate (error vs fp64 <= exact fp32's);
-#   "bf16"  opt-in reduced precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
+#   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
-_compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", "f32")
+_compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", "f32x3")
+if _compute_dtype not in ("f32", "f32x3", "bf16"):
+    raise ValueError(f"BM_COMPUTE_DTYPE must be f32, f32x3 or bf16, got {_compute_dtype!r}")
 
 
 def set_compute_dtype(name: str):

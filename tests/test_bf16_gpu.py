@@ -17,9 +17,10 @@ BF16_TOL = 1e-2
 @pytest.fixture()
 def bf16_mode():
     import brainmagick_amd
+    default = brainmagick_amd.get_compute_dtype()
     brainmagick_amd.set_compute_dtype("bf16")
     yield
-    brainmagick_amd.set_compute_dtype("f32")
+    brainmagick_amd.set_compute_dtype(default)
 
 
 @pytest.mark.parametrize("Cin,M,KS,dil,T,B", [(270, 320, 3, 1, 360, 3), (320, 320, 3, 16, 343, 2),

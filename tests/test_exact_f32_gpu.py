@@ -1,7 +1,10 @@
-"""Compute mode "f32x3": fp32-ACCURATE contractions on the bf16 matrix cores (exact 3-way bf16 split of
-both operands, six partial products, fp32 accumulate).  The mode is held to the SAME tolerances as the
-exact-fp32 MFMA kernels -- per-kernel forward rel-L2 <= 5e-6 vs fp64, gradients <= 2e-5, end-to-end
-1e-5 / 1e-4 / loss 1e-4 against the reference's golden vectors and the CPU oracle."""
+"""The two fp32-class compute modes side by side.
+
+The library default is "f32x3": fp32-ACCURATE contractions on the bf16 matrix cores (exact 3-way bf16
+split of both operands, six partial products, fp32 accumulate); every other GPU test file runs in it.
+This file re-runs the kernel, golden-vector and oracle suites in the OTHER mode, "f32" (exact-fp32 MFMA,
+v_mfma_f32_32x32x2_f32), at the SAME tolerances -- per-kernel forward rel-L2 <= 5e-6 vs fp64, gradients
+<= 2e-5, end-to-end 1e-5 / 1e-4 / loss 1e-4 -- and compares the two modes' errors directly."""
 import math
 
 import pytest
@@ -17,10 +20,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def x3_mode():
+    """(historical name) switches to the exact-fp32 MFMA mode for the test, then back to the default."""
     import brainmagick_amd
-    brainmagick_amd.set_compute_dtype("f32x3")
-    yield
+    default = brainmagick_amd.get_compute_dtype()
+    assert default == "f32x3"
     brainmagick_amd.set_compute_dtype("f32")
+    yield
+    brainmagick_amd.set_compute_dtype(default)
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +64,7 @@ def test_x3_error_is_fp32_class(H):
             _, y, _ = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda()), M, KS, dil)
             dw = H.gemm_nt(dy.cuda(), x.cuda(), B, M, Cin, T, KS, dil)[0]
         finally:
-            brainmagick_amd.set_compute_dtype("f32")
+            brainmagick_amd.set_compute_dtype("f32x3")
         errs[mode] = (rel_l2(y, ref), rel_l2(dw, wg.grad))
     print("rel-L2 vs fp64 (conv fwd, wgrad):", errs)
     for k in range(2):
