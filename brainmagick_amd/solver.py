@@ -24,7 +24,7 @@ class Solver:
                  optimizer: tp.Optional[FlatAdam] = None, device: str = "cuda",
                  offset_meg_ms: float = 0., sample_rate: float = 120., negatives: str = "local",
                  lr: float = 3e-4, betas=(0.9, 0.999), scale_reject=None,
-                 feature_model: tp.Optional[torch.nn.Module] = None):
+                 feature_model: tp.Optional[torch.nn.Module] = None, check_finite: bool = True):
         assert negatives in ("local", "node")
         self.device = torch.device(device)
         self.model = model.to(self.device)
@@ -42,6 +42,8 @@ class Solver:
         self.negatives = negatives
         self._gather = distrib.CandidateGather() if negatives == "node" else None
         self.scale_reject = scale_reject          # brainmagick_amd.norm.ScaleReject or None
+        self.check_finite = check_finite          # bm/solver.py:258-260 asserts (one fused host sync)
+        self._last_batch = None
 
     # -- bm/solver.py:230-321 ------------------------------------------------------------------
     def _process_batch(self, batch, training: bool = False):
@@ -55,6 +57,10 @@ class Solver:
         features_mask = batch.features_mask
         if len(meg) == 0:
             return None, None, None, None
+        if self.check_finite:
+            # bm/solver.py:258-260 (three separate asserts / syncs in the reference, one here)
+            assert bool(torch.isfinite(meg).all() & torch.isfinite(features).all()), \
+                "non-finite values in the MEG or feature tensors"
         if self.offset_meg_ms:
             # bm/solver.py:262-274: brain responses lag the audio by ~150 ms
             offset = int(self.offset_meg_ms / 1000 * self.sample_rate)
@@ -88,6 +94,14 @@ class Solver:
             m.train(True)
         self.loss.train(True)
         estimate, output, features_mask, _ = self._process_batch(batch, training=True)
+        if estimate is None:
+            # bm/solver.py:345-352: a fully rejected batch re-uses the last good one so that every
+            # rank keeps issuing the same collectives
+            if self._last_batch is None:
+                raise RuntimeError("Empty batch and last batch is none")
+            estimate, output, features_mask, _ = self._process_batch(self._last_batch, training=True)
+        else:
+            self._last_batch = batch
         output, target_offset = self._candidates(output)
         loss = self.loss(estimate, output, features_mask, target_offset=target_offset)
         # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path

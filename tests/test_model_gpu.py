@@ -481,3 +481,24 @@ def test_target_offset_matches_rolled_candidates():
         ref.backward()
         assert abs(float(loss) - float(ref)) < 1e-5
         assert rel_l2(e.grad, er.grad) < GRAD_TOL
+
+
+def test_rejected_batch_reuses_last_and_nonfinite_asserts():
+    """bm/solver.py:345-352 (empty batch -> last batch) and :258-260 (isfinite asserts)."""
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
+    model, _ = _small_model()
+    good = synthetic.make_batch(4, 20, 48, 10, 3, seed=1)
+    bad = synthetic.make_batch(4, 20, 48, 10, 3, seed=2)
+    bad.meg = bad.meg * 1e4
+    sr = ScaleReject(DeviceBatchScaler(torch.zeros(1, 20), torch.ones(1, 20)), limit=20, clip=False)
+    solver = Solver(model, scale_reject=sr)
+    with pytest.raises(RuntimeError, match="Empty batch"):
+        solver.train_step(bad)
+    l1 = solver.train_step(good)
+    l2 = solver.train_step(bad)                 # silently re-processes `good`
+    assert torch.isfinite(l1) and torch.isfinite(l2) and float(l2) < float(l1) + 1.0
+    nan = synthetic.make_batch(4, 20, 48, 10, 3, seed=3)
+    nan.features[0, 0, 0] = float("nan")
+    with pytest.raises(AssertionError):
+        Solver(_small_model()[0]).train_step(nan)
