@@ -18,12 +18,77 @@ struct ConvNNArgs {
     int ntiles_n, ntiles_m;
 };
 
+// Per-row epilogue parameters of a tile (bias, affine scale, affine shift) staged once into LDS:
+// ep[0..BM) = bias, ep[BM..2BM) = scale, ep[2BM..3BM) = shift.  Reading them from global memory per
+// element serialises hundreds of dependent L2 round trips per wavefront at the end of every tile.
+__device__ __forceinline__ void conv_ep_stage_params(const ConvNNArgs& a, float* ep, int BM, int m0, int tid,
+                                                     int nthreads) {
+    for (int i = tid; i < BM; i += nthreads) {
+        const int row = m0 + i;
+        const bool ok = row < a.M;
+        ep[i] = (a.bias && ok) ? a.bias[row] : 0.f;
+        ep[BM + i] = (a.ep_scale && ok) ? a.ep_scale[row] : 1.f;
+        ep[2 * BM + i] = (a.ep_shift && ok) ? a.ep_shift[row] : 0.f;
+    }
+}
+
+// One 32x32 accumulator block (C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)):
+// bias, optional pre-activation store, per-channel affine, activation, residual.  `rl0` = tile-local row of
+// element r = 0 of this lane (includes the 4 * (lane >> 5) term).  The column predicate is applied once
+// around the block, the row predicate only in tiles that straddle M (FULL = false), output pointers are
+// wave-uniform bases + one 32-bit lane offset, and the residual values of the block are fetched as one
+// batch of independent loads before anything is stored.
+template <bool FULL>
+__device__ __forceinline__ void conv_ep_block_stores(const ConvNNArgs& a, const float* ep, int BM, int b,
+                                                     int m0, int rl0, int col, const float (&v)[16]) {
+    const int row0 = m0 + rl0;
+    const int base = row0 * a.T + col;
+    float rv[16];
+    if (a.res) {
+        const float* rb = a.res + (long)b * a.res_bstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            rv[r] = (FULL || row0 + dr < a.M) ? rb[base + dr * a.T] : 0.f;
+        }
+    }
+    if (a.y_pre) {
+        float* yp = a.y_pre + (long)b * a.y_bstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (FULL || row0 + dr < a.M) yp[base + dr * a.T] = v[r];
+        }
+    }
+    if (a.y_out) {
+        float* yo = a.y_out + (long)b * a.y_bstride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const int rl = rl0 + dr;
+            float z = v[r] * ep[BM + rl] + ep[2 * BM + rl];
+            z = bm_act(z, a.act, a.leak);
+            if (a.res) z += rv[r];
+            if (FULL || row0 + dr < a.M) yo[base + dr * a.T] = z;
+        }
+    }
+}
+
+__device__ __forceinline__ void conv_ep_store_block(const ConvNNArgs& a, const f32x16& c, const float* ep,
+                                                    int BM, int b, int m0, int rl0, int col, float (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = c[r] + ep[rl0 + (r & 3) + 8 * (r >> 2)];
+    if (col < a.T) {
+        if (m0 + BM <= a.M) conv_ep_block_stores<true>(a, ep, BM, b, m0, rl0, col, v);
+        else conv_ep_block_stores<false>(a, ep, BM, b, m0, rl0, col, v);
+    }
+}
+
 // Epilogue for a [32*MT] x [128] tile held as MT 32x32 MFMA accumulators per wavefront (4 wavefronts,
 // wavefront w owns columns [32w, 32w+32)): bias, optional pre-activation store, optional per-tile
 // BatchNorm partial statistics, optional per-channel affine, activation, residual.
-// C/D layout of the 32x32 MFMA (dtype independent): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-// `tid` is the thread index inside the 4-wavefront group that owns the tile (a workgroup may hold
-// two such groups, one per segment); `smem` is that group's reduction scratch.
+// `tid` is the thread index inside the 4-wavefront group that owns the tile; `smem` is the workgroup's LDS,
+// free by now: [4 waves][BM][2] statistics scratch, then the 3 * BM staged row parameters.
 template <int MT>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvNNArgs& a, f32x16 (&acc)[MT], float* smem,
                                                    int b, int ntile, int m0, int n0, int tid) {
@@ -34,20 +99,20 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvNNArgs& a, f32x16 (
     const int h = lane >> 5;
     const int col = n0 + wave * 32 + nl;
     const bool col_ok = col < a.T;
-    float* red = smem;   // [4 waves][BM][2] for the BatchNorm partial statistics (LDS is free now)
+    float* red = smem;
+    float* ep = smem + 8 * BM;
+    __syncthreads();                 // every wavefront is done with the operand tiles
+    conv_ep_stage_params(a, ep, BM, m0, tid, 256);
+    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        float v[16];
+        conv_ep_store_block(a, acc[mt], ep, BM, b, m0, mt * 32 + 4 * h, col, v);
+        if (a.stats) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int row = m0 + rl;
-            const bool ok = col_ok && row < a.M;
-            float v = acc[mt][r];
-            if (a.bias && row < a.M) v += a.bias[row];
-            const long off = (long)row * a.T + col;
-            if (a.y_pre && ok) a.y_pre[(long)b * a.y_bstride + off] = v;
-            if (a.stats) {
-                float s = ok ? v : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int rl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float s = (col_ok && m0 + rl < a.M) ? v[r] : 0.f;
                 float s2 = s * s;
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) {
@@ -58,13 +123,6 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvNNArgs& a, f32x16 (
                     red[(wave * BM + rl) * 2 + 0] = s;
                     red[(wave * BM + rl) * 2 + 1] = s2;
                 }
-            }
-            if (a.y_out && ok) {
-                float z = v;
-                if (a.ep_scale) z = z * a.ep_scale[row] + a.ep_shift[row];
-                z = bm_act(z, a.act, a.leak);
-                if (a.res) z += a.res[(long)b * a.res_bstride + off];
-                a.y_out[(long)b * a.y_bstride + off] = z;
             }
         }
     }

@@ -202,7 +202,7 @@ static int launch_conv_nn_v(const ConvNNArgs& a, hipStream_t stream) {
     if (XW > 192)
         return bm_set_error(BM_ERR_UNSUPPORTED, "conv_nn: (kernel_size/2)*dilation = %d exceeds the 32-sample halo of the staged window", halo);
     size_t lds = (size_t)(2 * BM_BKC * BM + 2 * BM_BKC * XW) * sizeof(float);
-    const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+    const size_t lds_red = (size_t)(4 * BM * 2 + 3 * BM) * sizeof(float);   // epilogue scratch
     if (lds < lds_red) lds = lds_red;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_kernel<MT, VEC>),

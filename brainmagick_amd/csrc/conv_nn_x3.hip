@@ -16,6 +16,7 @@
 // stage = (chunk, tap): 2 k16-steps x 6 terms x MT MFMAs.  LDS is single-buffered (two barriers per
 // stage) so that two workgroups fit a CU; the next A slab and the next chunk's x window travel through
 // registers while the MFMAs run.
+#include <cstdlib>
 #include "conv_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -191,7 +192,7 @@ static int launch_conv_nn_x3(const ConvNNArgs& a, hipStream_t stream) {
     if (XW > 192)
         return bm_set_error(BM_ERR_UNSUPPORTED, "conv_nn_x3: (kernel_size/2)*dilation = %d exceeds the 32-sample halo", halo);
     size_t lds = (size_t)(3 * XG * BM + 3 * XG * XW) * 16;
-    const size_t lds_red = (size_t)4 * BM * 2 * sizeof(float);
+    const size_t lds_red = (size_t)(4 * BM * 2 + 3 * BM) * sizeof(float);   // epilogue scratch
     if (lds < lds_red) lds = lds_red;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_x3_kernel<MT, KS>),
@@ -204,6 +205,7 @@ static int launch_conv_nn_x3(const ConvNNArgs& a, hipStream_t stream) {
     return bm_check_launch("conv_nn_x3");
 }
 
+int bm_conv_nn_x3w_try(const ConvNNArgs& a, hipStream_t stream);   // conv_nn_x3w.hip
 extern "C" int bm_conv_bf16_mt_for(int M);
 extern "C" int bm_conv_bf16_mpad(int M);
 
@@ -282,6 +284,11 @@ extern "C" int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpack
     a.ntiles_n = cdiv(T, 128);
     a.ntiles_m = a.Mpad / (32 * mt);
     hipStream_t s = (hipStream_t)stream;
+    // large layers (M a multiple of 320): wide-tile kernel of conv_nn_x3w.hip
+    {
+        const int rc = bm_conv_nn_x3w_try(a, s);
+        if (rc >= 0) return rc;
+    }
 #define DISPATCH_KS(MT_)                                                  \
     switch (KS) {                                                         \
         case 1: return launch_conv_nn_x3<MT_, 1>(a, s);                   \

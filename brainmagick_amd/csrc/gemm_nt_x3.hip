@@ -27,7 +27,6 @@ struct GemmNTArgsX {
     float* part;
     int S, M, Cn, T, dil, nsplit, G;
     int tiles_m, tiles_c;
-    int vec;             // rows 16-byte aligned and T % 4 == 0: dwordx4 staging where the tap shift allows
 };
 
 template <int N> struct FVecD { typedef float type __attribute__((ext_vector_type(N))); };
@@ -47,15 +46,26 @@ __device__ __forceinline__ void split8x(const float* f, u32x4& hi, u32x4& mid, u
     lo = __builtin_bit_cast(u32x4, l);
 }
 
+// wave-uniform buffer descriptor over one segment: out-of-range dwords (rows past the end, t < 0 on the
+// first row) read as 0 without any per-lane predicate
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t seg_rsrc(const float* p, int bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 template <int WM, int WC, int MT, int NT, int KS>
-__global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX a) {
+__global__ __launch_bounds__(WM * WC * 64, (MT * NT * KS <= 3) ? 3 : 2) void gemm_nt_x3_kernel(GemmNTArgsX a) {
     constexpr int NW = WM * WC;
     constexpr int NTH = NW * 64;
     constexpr int BM = WM * MT * 32;
     constexpr int BC = WC * NT * 32;
     constexpr int AIT = BM * DSL / NTH;               // 8-sample items per thread (A)
-    constexpr int XIT = (KS * BC * DSL + NTH - 1) / NTH;   // 8-sample items per thread (all tap copies of X)
-    static_assert((BM * DSL) % NTH == 0, "A tile must split evenly");
+    constexpr int XPT = BC * DSL / NTH;               // 8-sample items per thread and tap (X)
+    constexpr int XIT = KS * XPT;
+    static_assert((BM * DSL) % NTH == 0 && (BC * DSL) % NTH == 0, "tiles must split evenly over the threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* As = reinterpret_cast<u32x4*>(smem);       // [3 planes][BM][SLOTS]
     u32x4* Xs = As + 3 * BM * SLOTS;                  // [3 planes][KS][BC][SLOTS]
@@ -79,6 +89,9 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
     const long nchunks = (long)(s_end - s_begin) * cps;
     const long q_begin = nchunks * split / a.nsplit;
     const long q_end = nchunks * (split + 1) / a.nsplit;
+    const int halo = (KS >> 1) * a.dil;
+    const int a_bytes = (int)(((long)(a.M - 1) * a.a_rstride + a.T) * 4);
+    const int x_bytes = (int)(((long)(a.Cn - 1) * a.x_rstride + a.T) * 4);
 
     f32x16 acc[MT][NT][KS];
 #pragma unroll
@@ -93,51 +106,67 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
     typename FVecD<8 * AIT>::type areg;
     typename FVecD<8 * XIT>::type xreg;
 
-    // 8 consecutive samples row[t .. t+7], zero outside [0, T); dwordx4 pairs when aligned
-#define LOAD8(DST_, OFF_, ROW_, T_, OK_, ALIGNED_)                                                \
+    // per-thread element offsets inside a segment (row * stride + 8 * slot), fixed for the whole kernel
+    int a_off[AIT], x_off[XPT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        const int e = tid + i * NTH;
+        a_off[i] = (m0 + (e >> 2)) * (int)a.a_rstride + 8 * (e & 3);
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int e = tid + i * NTH;
+        x_off[i] = (c0 + (e >> 2)) * (int)a.x_rstride + 8 * (e & 3);
+    }
+
+    // interior chunks: 8 consecutive samples starting at element offset OFF_ (>= 0) of the segment behind
+    // RS_ as two dwordx4 buffer loads (dword alignment is all the hardware asks for, so every tap shift
+    // takes this path); rows past the end of the segment come back as 0 from the buffer bounds check
+#define LOAD8(DST_, D0_, RS_, OFF_)                                                               \
     {                                                                                             \
-        if ((ALIGNED_)) {                                                                         \
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;                                 \
-            if ((OK_) && (T_) >= 0 && (T_) < a.T) v0 = *reinterpret_cast<const float4*>((ROW_) + (T_));         \
-            if ((OK_) && (T_) + 4 >= 0 && (T_) + 4 < a.T) v1 = *reinterpret_cast<const float4*>((ROW_) + (T_) + 4); \
-            DST_[OFF_] = v0.x; DST_[OFF_ + 1] = v0.y; DST_[OFF_ + 2] = v0.z; DST_[OFF_ + 3] = v0.w; \
-            DST_[OFF_ + 4] = v1.x; DST_[OFF_ + 5] = v1.y; DST_[OFF_ + 6] = v1.z; DST_[OFF_ + 7] = v1.w; \
-        } else if ((OK_) && (T_) >= 0 && (T_) + 8 <= a.T) {                                       \
-            /* interior run: one address, eight immediate-offset dword loads */                   \
-            const float* p8 = (ROW_) + (T_);                                                      \
-            _Pragma("unroll") for (int r = 0; r < 8; ++r) DST_[OFF_ + r] = p8[r];                 \
-        } else {                                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                       \
-                const int tt = (T_) + r;                                                          \
-                DST_[OFF_ + r] = ((OK_) && tt >= 0 && tt < a.T) ? (ROW_)[tt] : 0.f;               \
-            }                                                                                     \
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(RS_, (OFF_) * 4, 0, 0);            \
+        const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(RS_, (OFF_) * 4 + 16, 0, 0);       \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                           \
+            DST_[D0_ + r] = __uint_as_float(v0[r]);                                               \
+            DST_[D0_ + 4 + r] = __uint_as_float(v1[r]);                                           \
         }                                                                                         \
     }
-#define NT_LOAD(Q_)                                                                               \
+    // edge chunks (wave-uniform, the first / last chunks of a segment): one dword per sample, samples whose
+    // time index falls outside [0, T) get an out-of-range offset and therefore read as 0.  (A negative
+    // voffset must never meet a positive immediate offset: the bounds check does not wrap.)
+#define LOAD8E(DST_, D0_, RS_, OFF_, T_)                                                          \
     {                                                                                             \
-        const int sl = (int)((Q_) / cps);                                                         \
-        const int t0 = (int)((Q_) - (long)sl * cps) * BKT2;                                       \
-        int sidx = s_begin + sl;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                           \
+            const int tt = (T_) + r;                                                              \
+            const int off = (tt >= 0 && tt < a.T) ? ((OFF_) + r) * 4 : 0x7ffffff0;                \
+            DST_[D0_ + r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(RS_, off, 0, 0)); \
+        }                                                                                         \
+    }
+#define NT_LOAD()        /* stages chunk (ld_s, ld_c) and advances the cursor */                  \
+    {                                                                                             \
+        const int t0 = ld_c * BKT2;                                                               \
+        int sidx = s_begin + ld_s;                                                                \
         if (a.order) sidx = a.order[sidx];                                                        \
-        const float* ab = a.a + (long)sidx * a.a_sstride;                                         \
-        const float* xb = a.x + (long)sidx * a.x_sstride;                                         \
-        _Pragma("unroll") for (int i = 0; i < AIT; ++i) {                                         \
-            const int e = tid + i * NTH;                                                          \
-            const int row = e >> 2, q = e & 3;                                                    \
-            const int m = m0 + row;                                                               \
-            const float* rp = ab + (long)m * a.a_rstride;                                         \
-            LOAD8(areg, 8 * i, rp, t0 + 8 * q, m < a.M, a.vec)                                    \
+        const __amdgpu_buffer_rsrc_t ra = seg_rsrc(a.a + (long)sidx * a.a_sstride, a_bytes);      \
+        const __amdgpu_buffer_rsrc_t rx = seg_rsrc(a.x + (long)sidx * a.x_sstride, x_bytes);      \
+        if (t0 - halo < 0 || t0 + BKT2 + halo > a.T) {                                            \
+            _Pragma("unroll") for (int i = 0; i < AIT; ++i)                                       \
+                LOAD8E(areg, 8 * i, ra, a_off[i] + t0, t0 + 8 * ((tid + i * NTH) & 3))            \
+            _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                      \
+                const int shift = (j - (KS >> 1)) * a.dil;                                        \
+                _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                   \
+                    LOAD8E(xreg, 8 * (j * XPT + i), rx, x_off[i] + t0 + shift,                    \
+                           t0 + shift + 8 * ((tid + i * NTH) & 3))                                \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < AIT; ++i) LOAD8(areg, 8 * i, ra, a_off[i] + t0)  \
+            _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                      \
+                const int shift = (j - (KS >> 1)) * a.dil;                                        \
+                _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                   \
+                    LOAD8(xreg, 8 * (j * XPT + i), rx, x_off[i] + t0 + shift)                     \
+            }                                                                                     \
         }                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < XIT; ++i) {                                         \
-            const int e = tid + i * NTH;                                                          \
-            const int j = e / (BC * DSL);                                                         \
-            const int rem = e - j * (BC * DSL);                                                   \
-            const int row = rem >> 2, q = rem & 3;                                                \
-            const int c = c0 + row;                                                               \
-            const int shift = (j - (KS >> 1)) * a.dil;                                            \
-            const float* rp = xb + (long)c * a.x_rstride;                                         \
-            LOAD8(xreg, 8 * i, rp, t0 + 8 * q + shift, j < KS && c < a.Cn, a.vec && ((shift & 3) == 0)) \
-        }                                                                                         \
+        if (++ld_c == cps) { ld_c = 0; ++ld_s; }                                                  \
     }
 #define NT_STORE()                                                                                \
     {                                                                                             \
@@ -150,29 +179,28 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
             const int slot = SWZ(e >> 2, e & 3);                                                  \
             As[slot] = hi; As[BM * SLOTS + slot] = mid; As[2 * BM * SLOTS + slot] = lo;           \
         }                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < XIT; ++i) {                                         \
-            const int e = tid + i * NTH;                                                          \
-            const int j = e / (BC * DSL);                                                         \
-            const int rem = e - j * (BC * DSL);                                                   \
-            if (j < KS) {                                                                         \
+        _Pragma("unroll") for (int j = 0; j < KS; ++j)                                            \
+            _Pragma("unroll") for (int i = 0; i < XPT; ++i) {                                     \
+                const int e = tid + i * NTH;                                                      \
                 float f[8];                                                                       \
-                _Pragma("unroll") for (int r = 0; r < 8; ++r) f[r] = xreg[8 * i + r];             \
+                _Pragma("unroll") for (int r = 0; r < 8; ++r) f[r] = xreg[8 * (j * XPT + i) + r]; \
                 u32x4 hi, mid, lo;                                                                \
                 split8x(f, hi, mid, lo);                                                          \
-                const int slot = j * BC * SLOTS + SWZ(rem >> 2, rem & 3);                         \
+                const int slot = j * BC * SLOTS + SWZ(e >> 2, e & 3);                             \
                 Xs[slot] = hi; Xs[KS * BC * SLOTS + slot] = mid; Xs[2 * KS * BC * SLOTS + slot] = lo; \
             }                                                                                     \
-        }                                                                                         \
     }
 
+    int ld_s = (int)(q_begin / cps);
+    int ld_c = (int)(q_begin - (long)ld_s * cps);
     if (q_begin < q_end) {
-        NT_LOAD(q_begin);
+        NT_LOAD();
         NT_STORE();
     }
     __syncthreads();
     for (long q = q_begin; q < q_end; ++q) {
         const bool more = q + 1 < q_end;
-        if (more) NT_LOAD(q + 1);
+        if (more) NT_LOAD();
         // row-per-lane operand reads; rows of the 32-row MFMA blocks start at multiples of 32, so the
         // swizzle term only depends on the lane's row-in-block nl
         const u32x4* ap = As + (wm * MT * 32 + nl) * SLOTS;
@@ -220,6 +248,7 @@ __global__ __launch_bounds__(WM * WC * 64, 2) void gemm_nt_x3_kernel(GemmNTArgsX
 #undef NT_LOAD
 #undef NT_STORE
 #undef LOAD8
+#undef LOAD8E
 
     const long N = (long)a.Cn * KS;
     float* dst = a.part + (long)(g * a.nsplit + split) * a.M * N;
@@ -272,8 +301,6 @@ extern "C" int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, con
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride;
     g.order = order; g.seg = seg; g.part = part;
     g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit; g.G = G;
-    g.vec = (T % 4 == 0) && (a_rstride % 4 == 0) && (x_rstride % 4 == 0) && (a_sstride % 4 == 0) &&
-            (x_sstride % 4 == 0) && (((uintptr_t)a | (uintptr_t)x) % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
     const bool bigM = prefer_big_x(M);
     if (KS == 1) {

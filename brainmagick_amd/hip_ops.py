@@ -164,7 +164,9 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     if _timer is not None:
         label = {"f32": f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>",
                  "bf16": f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>",
-                 "f32x3": f"conv_nn_x3_kernel<{lib().bm_conv_bf16_mt_for(M)}>"}[mode]
+                 "f32x3": (f"conv_nn_x3w_kernel<{KS}>"
+                           if mode == "f32x3" and lib().bm_conv_x3_is_wide(Cin, M, T, KS, dil, int(want_stats))
+                           else f"conv_nn_x3_kernel<{lib().bm_conv_bf16_mt_for(M)}>")}[mode]
         _timer.launch(label, 2.0 * B * T * M * Cin * KS, launch)
     else:
         launch()

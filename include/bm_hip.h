@@ -81,6 +81,10 @@ int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpacked, const i
                     const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                     int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
+/* 1 when bm_conv1d_nn_x3 takes the wide-tile kernel (conv_nn_x3w.hip: 320 x 192 workgroup tile, one
+ * wavefront per SIMD, weight slabs by LDS DMA) for this shape, 0 for conv_nn_x3_kernel.  Used by the
+ * host-side kernel timer to label launches the way rocprofv3 names them. */
+int bm_conv_x3_is_wide(int Cin, int M, int T, int KS, int dil, int with_stats);
 int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                   long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                   int Cn, int T, int KS, int dil, int nsplit, void* stream);
