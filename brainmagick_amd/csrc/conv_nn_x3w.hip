@@ -156,7 +156,13 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
     for (int c16 = 0; c16 < n16; ++c16) {
 #pragma unroll
         for (int j = 0; j < KS; ++j, ++s) {
-            // this stage's operand fragments first, in the order the partial products consume them
+            // next stage's weight slab by DMA first: it has the whole stage to land (the last stage re-copies
+            // its own slab: no branches inside a stage)
+#ifndef WIDE_EXP_NODMA
+            DMA_A(s + 1 < nstage ? s + 1 : s);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // this stage's operand fragments, in the order the partial products consume them
             const u32x4* ab = As + (s & 1) * WASLAB + h * WBM + wm * (MW * 32) + nl;
             const u32x4* xb = Xs + (c16 & 1) * WXSLAB + h * WXWP + wn * (NW * 32) + nl + j * a.dil;
             bf16x8 af[3][MW], bf[3][NW];
@@ -167,16 +173,17 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
         af[PA_][mt] = __builtin_bit_cast(bf16x8, ab[(PA_) * 2 * WBM + mt * 32]);
             FRAGS(2, 0) FRAGS(0, 2) FRAGS(1, 1)
 #undef FRAGS
-            // next stage's weight slab by DMA, next chunk's input window into registers (the last stage
-            // re-copies its own slab / reads zeros: no branches inside a stage)
-            DMA_A(s + 1 < nstage ? s + 1 : s);
-            if (j == 0) LOAD_X(c16 + 1);
+#ifndef WIDE_EXP_NOX
+            if (j == 0) LOAD_X(c16 + 1);   // next chunk's input window into registers (zeros past the last chunk)
+#endif
             PSTAMP(0)
 #ifdef WIDE_PROFILE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             PSTAMP(1)
+#ifndef WIDE_EXP_NOX
             if (j == KS - 1) STORE_X((c16 + 1) & 1);
+#endif
             // six partial products, smallest first (planes: 0 = hi, 1 = mid, 2 = lo)
 #define TERM(PA_, PB_)                                                                            \
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
@@ -186,7 +193,9 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
 #undef TERM
             PSTAMP(2)
             PSTAMP(3)
+#ifndef WIDE_EXP_NOBARRIER
             __syncthreads();      // next A slab landed (vmcnt) and visible, this stage's LDS reads are done
+#endif
             PSTAMP(4)
         }
     }

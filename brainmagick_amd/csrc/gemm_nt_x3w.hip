@@ -1,0 +1,306 @@
+// Wide-tile variant of the fp32-accurate ("f32x3") time-contraction GEMM of gemm_nt_x3.hip for the
+// weight gradients of the conv stack (M a multiple of 320, Cn a multiple of 64, 3 taps, one group):
+//
+//   part[split][m][c*3 + j] = sum_{s, t in split} A[s][m][t] * X[s][c][t + (j - 1) * dil]
+//
+// ONE workgroup of four wavefronts per CU (one per SIMD); a wavefront owns 160 rows x (32 channels x 3
+// taps) as 5 x 3 MFMA accumulators (240 registers), the workgroup 320 x (64 x 3).  With 1 x 1 x 3 blocks
+// per wavefront (gemm_nt_x3.hip) the exact 3-way bf16 split of the operands costs ~9 VALU instructions
+// per MFMA and the kernel is VALU-bound; here it is ~2 per MFMA and is interleaved with the MFMAs of
+// the same wavefront.  Stage = 16 samples: 4 items of 8 samples per thread (A rows 0..319, then the three
+// tap-shifted copies of the 64 X rows), fetched two stages ahead with bounds-checked dwordx4 buffer loads
+// (dword alignment suffices, so every tap shift takes the wide path), split and written into the other
+// LDS buffer while the 90 MFMAs of the current stage run.
+// LDS (16-byte slots = 8 samples of one plane): A [2][3 planes][320 rows][2], X [2][3][3 taps][64][2] = 96 KB.
+#include <cstdlib>
+#include "bm_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define GW_BM 320
+#define GW_BC 64
+#define GW_K 16
+#define GW_ASLOTS (GW_BM * 2)                 // 16-byte slots of one plane of the A tile
+#define GW_XSLOTS (3 * GW_BC * 2)             // ... of the X tile (3 taps)
+#define GW_BUF (3 * (GW_ASLOTS + GW_XSLOTS))  // slots of one stage buffer (3 planes)
+
+struct GemmNTArgsW {
+    const float* a; long a_sstride; long a_rstride;
+    const float* x; long x_sstride; long x_rstride;
+    float* part;
+    int S, M, Cn, T, dil, nsplit;
+    int tiles_m, tiles_c;
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (base, stride 0, num_records = bytes, 32-bit data format) in four SGPRs
+__device__ __forceinline__ i32x4 gw_rsrc(const float* p, int bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    d[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(u >> 32) & 0xffffu));
+    d[2] = __builtin_amdgcn_readfirstlane(bytes);
+    d[3] = 0x00020000;
+    return d;
+}
+
+// The staging loads are issued through inline asm so that the compiler's waitcnt pass does not see them: it
+// would drain the queue (vmcnt(0)) at the first use of the older register set and so stall every stage on
+// the loads it has just issued.  The matching counted waits are GW_WAIT below; until then the destination
+// registers must not be read (they are only read by the split that follows the wait).
+__device__ __forceinline__ u32x4 gw_ld128(i32x4 rs, int voff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned gw_ld32(i32x4 rs, int voff) {
+    unsigned v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
+
+// exact 3-way split of 8 fp32 values into bf16 planes and store into the three plane tiles
+__device__ __forceinline__ void gw_split_store(const float (&f)[8], u32x4* dst, int plane_stride) {
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 a = (__bf16)f[i];
+        const float r1 = f[i] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        h[i] = a; m[i] = b; l[i] = (__bf16)(r1 - (float)b);
+    }
+    dst[0] = __builtin_bit_cast(u32x4, h);
+    dst[plane_stride] = __builtin_bit_cast(u32x4, m);
+    dst[2 * plane_stride] = __builtin_bit_cast(u32x4, l);
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
+    constexpr int MW = 5;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem);      // [2 buffers][3 planes][A slots | X slots]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wc = wave & 1;
+    const int nl = lane & 31, h = lane >> 5;
+
+    int id = bm_xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id % a.tiles_m; id /= a.tiles_m;
+    const int tc = id % a.tiles_c;
+    const int split = id / a.tiles_c;
+    const int m0 = tm * GW_BM, c0 = tc * GW_BC;
+
+    const int cps = (a.T + GW_K - 1) / GW_K;
+    const long nchunks = (long)a.S * cps;
+    const long q_begin = nchunks * split / a.nsplit;
+    const long q_end = nchunks * (split + 1) / a.nsplit;
+    const int nst = (int)(q_end - q_begin);
+    const int halo = a.dil;
+    const int a_bytes = (int)(((long)(a.M - 1) * a.a_rstride + a.T) * 4);
+    const int x_bytes = (int)(((long)(a.Cn - 1) * a.x_rstride + a.T) * 4);
+
+    // the four 8-sample items of this thread.  Items 0, 1: A rows 0..255; item 2: A rows 256..319
+    // (wavefronts 0, 1) or tap 0 of X (wavefronts 2, 3); item 3: taps 1 / 2 of X.  Which operand an item
+    // belongs to is wave-uniform.  LDS slot inside a plane: A -> e, X -> GW_ASLOTS + (e - 640).
+    const bool i2_is_a = wave < 2;
+    const int tap3 = wave < 2 ? 1 : 2;
+    int off[4], sh[4];                                 // element offset inside the segment, tap shift
+    off[0] = (m0 + (tid >> 1)) * (int)a.a_rstride + 8 * (tid & 1);
+    off[1] = (m0 + 128 + (tid >> 1)) * (int)a.a_rstride + 8 * (tid & 1);
+    off[2] = i2_is_a ? (m0 + 256 + (tid >> 1)) * (int)a.a_rstride + 8 * (tid & 1)
+                     : (c0 + ((tid - 128) >> 1)) * (int)a.x_rstride + 8 * (tid & 1);
+    off[3] = (c0 + ((tid & 127) >> 1)) * (int)a.x_rstride + 8 * (tid & 1);
+    sh[0] = 0; sh[1] = 0;
+    sh[2] = i2_is_a ? 0 : -a.dil;
+    sh[3] = (tap3 - 1) * a.dil;
+    const int slot2 = i2_is_a ? 512 + tid : GW_ASLOTS + (tid - 128);
+    const int slot3 = GW_ASLOTS + 128 + tid;
+
+    f32x16 acc[MW][3];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4][2], rb[4][2];                          // two staging register sets (two stages in flight)
+
+    int ld_s = (int)(q_begin / cps);
+    int ld_c = (int)(q_begin - (long)ld_s * cps);
+
+    // loads chunk (ld_s, ld_c) into register set R_ and advances the cursor.  Interior chunks: two dwordx4
+    // per item.  Edge chunks (first / last of a segment, wave-uniform): one dword per sample, samples whose
+    // time index is outside [0, T) get an out-of-range offset and read as 0.
+#define GW_LOAD(R_)                                                                               \
+    {                                                                                             \
+        const int t0 = ld_c * GW_K;                                                               \
+        const i32x4 qa = gw_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                        \
+        const i32x4 qx = gw_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                        \
+        const i32x4 q2 = i2_is_a ? qa : qx;                                                       \
+        if (!(t0 - halo < 0 || t0 + GW_K + halo > a.T)) {                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                const i32x4 rs = i < 2 ? qa : i == 2 ? q2 : qx;                                   \
+                const int o = (off[i] + t0 + sh[i]) * 4;                                          \
+                R_[i][0] = gw_ld128(rs, o);                                                       \
+                R_[i][1] = gw_ld128(rs, o + 16);                                                  \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                const i32x4 rs = i < 2 ? qa : i == 2 ? q2 : qx;                                   \
+                const int o = off[i] + t0 + sh[i];                                                \
+                const int tt0 = t0 + 8 * (tid & 1) + sh[i];                                       \
+                _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                   \
+                    const int tt = tt0 + r;                                                       \
+                    const int oo = (tt >= 0 && tt < a.T) ? (o + r) * 4 : 0x7ffffff0;              \
+                    R_[i][r >> 2][r & 3] = gw_ld32(rs, oo);                                       \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+        if (++ld_c == cps) { ld_c = 0; ++ld_s; }                                                  \
+    }
+    // counted wait for register set R_: at most N_ younger load instructions may stay in flight.  (After an
+    // edge chunk 32 instead of 8 younger loads are outstanding: vmcnt(8) then over-waits, which is safe.)
+#define GW_WAIT(R_, N_)                                                                           \
+    asm volatile("s_waitcnt vmcnt(" #N_ ")"                                                       \
+                 : "+v"(R_[0][0]), "+v"(R_[0][1]), "+v"(R_[1][0]), "+v"(R_[1][1]), "+v"(R_[2][0]), \
+                   "+v"(R_[2][1]), "+v"(R_[3][0]), "+v"(R_[3][1])::"memory");
+    // splits item I_ of register set R_ into buffer BUF_
+#define GW_STORE(R_, I_, BUF_)                                                                    \
+    {                                                                                             \
+        const int slot = (I_) == 0 ? tid : (I_) == 1 ? 256 + tid : (I_) == 2 ? slot2 : slot3;     \
+        float f_[8];                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) f_[r] = __uint_as_float(R_[I_][r >> 2][r & 3]); \
+        gw_split_store(f_, lds + (BUF_) * GW_BUF + slot, GW_ASLOTS + GW_XSLOTS);                  \
+    }
+#define GW_TERM(PA_, PB_)                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                             \
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA_][mt], bf[PB_][j], acc[mt][j], 0, 0, 0);
+    // one stage: MFMAs on buffer BUF_, prefetch into LD_ (if MORE2_), split ST_ into the other buffer (if MORE1_)
+#define GW_STAGE(BUF_, LD_, ST_, MORE2_, MORE1_)                                                  \
+    {                                                                                             \
+        const u32x4* pb = lds + (BUF_) * GW_BUF;                                                  \
+        const u32x4* ab = pb + (wm * (MW * 32) + nl) * 2 + h;                                     \
+        const u32x4* xb = pb + GW_ASLOTS + (wc * 32 + nl) * 2 + h;                                \
+        constexpr int PS = GW_ASLOTS + GW_XSLOTS;                                                 \
+        bf16x8 af[3][MW], bf[3][3];                                                               \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[0][j] = __builtin_bit_cast(bf16x8, xb[0 * PS + j * GW_BC * 2]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[2][mt] = __builtin_bit_cast(bf16x8, ab[2 * PS + mt * 64]); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[2][j] = __builtin_bit_cast(bf16x8, xb[2 * PS + j * GW_BC * 2]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(bf16x8, ab[0 * PS + mt * 64]); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[1][j] = __builtin_bit_cast(bf16x8, xb[1 * PS + j * GW_BC * 2]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(bf16x8, ab[1 * PS + mt * 64]); \
+        if (MORE2_) GW_LOAD(LD_)                                                                  \
+        GW_TERM(2, 0)                                                                             \
+        if (MORE1_) { if (MORE2_) GW_WAIT(ST_, 8) else GW_WAIT(ST_, 0) }                          \
+        if (MORE1_) GW_STORE(ST_, 0, (BUF_) ^ 1)                                                  \
+        GW_TERM(0, 2)                                                                             \
+        if (MORE1_) GW_STORE(ST_, 1, (BUF_) ^ 1)                                                  \
+        GW_TERM(1, 1)                                                                             \
+        if (MORE1_) GW_STORE(ST_, 2, (BUF_) ^ 1)                                                  \
+        GW_TERM(1, 0)                                                                             \
+        if (MORE1_) GW_STORE(ST_, 3, (BUF_) ^ 1)                                                  \
+        GW_TERM(0, 1)                                                                             \
+        GW_TERM(0, 0)                                                                             \
+        /* spread the split arithmetic between the MFMAs: one MFMA, then up to three VALU ops */  \
+        _Pragma("unroll") for (int g_ = 0; g_ < 75; ++g_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
+        }                                                                                         \
+        __syncthreads();                                                                          \
+    }
+
+    if (nst > 0) {
+        GW_LOAD(ra)
+        if (nst > 1) GW_LOAD(rb)
+        GW_WAIT(ra, 0)
+        if (nst > 1) GW_WAIT(rb, 0)
+        GW_STORE(ra, 0, 0) GW_STORE(ra, 1, 0) GW_STORE(ra, 2, 0) GW_STORE(ra, 3, 0)
+        __syncthreads();
+        // stage k: MFMAs on buffer k & 1, chunk k + 1 (registers) -> buffer (k + 1) & 1, chunk k + 2 -> registers
+        int k = 0;
+        for (; k + 3 < nst; k += 2) {                  // steady state: no branches inside a stage
+            GW_STAGE(0, ra, rb, true, true)
+            GW_STAGE(1, rb, ra, true, true)
+        }
+        // last one to three stages (k is even)
+        GW_STAGE(0, ra, rb, k + 2 < nst, k + 1 < nst)
+        if (k + 1 < nst) GW_STAGE(1, rb, ra, false, k + 2 < nst)
+        if (k + 2 < nst) GW_STAGE(0, ra, rb, false, false)
+    }
+#undef GW_LOAD
+#undef GW_WAIT
+#undef GW_STORE
+#undef GW_TERM
+#undef GW_STAGE
+
+    // partial tile out: part[split][m][c * 3 + j]
+    const long N = (long)a.Cn * 3;
+    float* dst = a.part + (long)split * a.M * N;
+    const int c = c0 + wc * 32 + nl;
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (MW * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < a.M && c < a.Cn) {
+                float* p = dst + (long)m * N + (long)c * 3;
+                p[0] = acc[mt][0][r];
+                p[1] = acc[mt][1][r];
+                p[2] = acc[mt][2][r];
+            }
+        }
+    }
+}
+
+static bool gw_covers(int S, int G, int M, int Cn, int T, int KS, int dil, bool ordered) {
+    static int wide = -1;
+    if (wide < 0) {
+        const char* e = getenv("BM_X3_WIDE");          // BM_X3_WIDE=0: A/B runs against gemm_nt_x3_kernel
+        wide = !(e && e[0] == '0');
+    }
+    if (!wide || G != 1 || ordered || KS != 3) return false;
+    if (M % GW_BM != 0 || Cn % GW_BC != 0 || dil < 1 || dil > 32 || T < 2 * GW_K) return false;
+    return (long)S * ((T + GW_K - 1) / GW_K) >= 64;
+}
+
+// Split count for bm_gemm_nt_x3: when the wide kernel covers the shape, one workgroup per CU per round
+// (256 CUs); otherwise the generic rule of bm_gemm_nt_suggest_splits.
+extern "C" int bm_gemm_nt_suggest_splits(int M, int Cn, int KS, int S, int T, int G);
+extern "C" int bm_gemm_nt_x3_suggest_splits(int M, int Cn, int KS, int S, int T, int G, int dil) {
+    if (!gw_covers(S, G, M, Cn, T, KS, dil, false)) return bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G);
+    const int tiles = (M / GW_BM) * (Cn / GW_BC);
+    long chunks = (long)S * ((T + GW_K - 1) / GW_K);
+    long want = 256 / tiles;
+    if (want < 1) want = 1;
+    if (want > chunks / 32) want = chunks / 32;        // >= 32 stages per workgroup
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+// returns -1 when the shape is not covered (the caller then takes gemm_nt_x3_kernel)
+int bm_gemm_nt_x3w_try(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
+                       long x_rstride, const int* order, float* part, int S, int G, int M, int Cn, int T,
+                       int KS, int dil, int nsplit, hipStream_t stream) {
+    if (!gw_covers(S, G, M, Cn, T, KS, dil, order != nullptr)) return -1;
+    if ((long)M * a_rstride * 4 >= 0x7f000000L || (long)Cn * x_rstride * 4 >= 0x7f000000L) return -1;
+    GemmNTArgsW g;
+    g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride;
+    g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride;
+    g.part = part; g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit;
+    g.tiles_m = M / GW_BM; g.tiles_c = Cn / GW_BC;
+    const size_t lds = (size_t)2 * GW_BUF * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x3w_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt_x3w: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long nblocks = (long)g.tiles_m * g.tiles_c * nsplit;
+    hipLaunchKernelGGL(gemm_nt_x3w_kernel, dim3((unsigned)nblocks), dim3(256), lds, stream, g);
+    return bm_check_launch("gemm_nt_x3w");
+}

@@ -205,8 +205,12 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         out_strides = (M * Cn * KS, Cn * KS, KS, 1)
     if out is None:
         out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
+    mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
     if nsplit is None:
-        nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G)
+        if mode == "f32x3" and order is None:
+            nsplit = lib().bm_gemm_nt_x3_suggest_splits(M, Cn, KS, S, T, G, dil)
+        else:
+            nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G)
         if G > 1:
             tiles = max(1, (M // 64) * (Cn // 64)) * G
             nsplit = max(1, min(8, 512 // tiles)) if T >= 1024 else 1
@@ -215,7 +219,6 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = out
     else:
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
-    mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
     fn = {"f32": lib().bm_gemm_nt, "bf16": lib().bm_gemm_nt_bf16, "f32x3": lib().bm_gemm_nt_x3}[mode]
 
     def launch():

@@ -88,6 +88,9 @@ int bm_conv_x3_is_wide(int Cin, int M, int T, int KS, int dil, int with_stats);
 int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                   long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                   int Cn, int T, int KS, int dil, int nsplit, void* stream);
+/* split count bm_gemm_nt_x3 wants for this shape (one 320 x 64 x 3-tap workgroup per CU when the wide-tile
+ * kernel of gemm_nt_x3w.hip covers it, else bm_gemm_nt_suggest_splits). */
+int bm_gemm_nt_x3_suggest_splits(int M, int Cn, int KS, int S, int T, int G, int dil);
 int bm_gemm_nt_bf16(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                     long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                     int Cn, int T, int KS, int dil, int nsplit, void* stream);

@@ -37,6 +37,10 @@ CONV_CASES = [
     (33, 40, 5, 8, 100, 2),
     (16, 16, 3, 4, 7, 1),      # T smaller than the dilation halo
     (5, 1024, 1, 1, 130, 1),
+    # shapes the wide-tile f32x3 kernels cover (conv_nn_x3w / gemm_nt_x3w: M % 320 == 0, Cin % 64 == 0)
+    (320, 320, 3, 2, 360, 4),
+    (64, 640, 3, 16, 343, 3),
+    (128, 320, 3, 1, 361, 3),
 ]
 
 
@@ -77,7 +81,7 @@ def test_conv_nn_epilogue_and_stats(H):
         assert rel_l2(s[:, 1], (pre_ref ** 2).sum((0, 2))) < 1e-5
 
 
-@pytest.mark.parametrize("Cin,M,KS,dil,T,B", CONV_CASES[:7])
+@pytest.mark.parametrize("Cin,M,KS,dil,T,B", CONV_CASES[:7] + CONV_CASES[9:])
 def test_conv_backward_kernels(H, Cin, M, KS, dil, T, B):
     g = _gen(Cin + M * 3 + KS + dil + T)
     x = torch.randn(B, Cin, T, generator=g, dtype=torch.float64, requires_grad=True)
@@ -92,7 +96,7 @@ def test_conv_backward_kernels(H, Cin, M, KS, dil, T, B):
     dw = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil)
     assert dw.shape == (1, M, Cin, KS)
     assert rel_l2(dw[0], w.grad) < GRAD_TOL
-    for nsplit in (1, 3):
+    for nsplit in (1, 3, 4):
         dw2 = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil, nsplit=nsplit)
         assert rel_l2(dw2[0], w.grad) < GRAD_TOL
 
