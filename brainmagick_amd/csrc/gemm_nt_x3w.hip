@@ -8,10 +8,15 @@
 // per wavefront (gemm_nt_x3.hip) the exact 3-way bf16 split of the operands costs ~9 VALU instructions
 // per MFMA and the kernel is VALU-bound; here it is ~2 per MFMA and is interleaved with the MFMAs of
 // the same wavefront.  Stage = 16 samples: 4 items of 8 samples per thread (A rows 0..319, then the three
-// tap-shifted copies of the 64 X rows), fetched two stages ahead with bounds-checked dwordx4 buffer loads
+// tap-shifted copies of the 64 X rows), fetched three stages ahead with bounds-checked dwordx4 buffer loads
 // (dword alignment suffices, so every tap shift takes the wide path), split and written into the other
 // LDS buffer while the 90 MFMAs of the current stage run.
-// LDS (16-byte slots = 8 samples of one plane): A [2][3 planes][320 rows][2], X [2][3][3 taps][64][2] = 96 KB.
+// LDS (16-byte slots = 8 samples of one plane), three stage buffers of three planes each:
+//   A [2 halves of the 16 samples][320 + 8 rows], X [3 taps][2 halves][64 + 8 rows]   (153 KB in all).
+// Rows are contiguous inside a half (the row-per-lane ds_read_b128 of an MFMA operand reads 512 contiguous
+// bytes per half-wavefront); the 8 pad rows put the two halves 32 banks apart for the staging writes
+// (adjacent lanes = the two halves of one row).  rocprofv3: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33,
+// LDS ~19 % busy - not what bounds the kernel.
 #include <cstdlib>
 #include "bm_common.h"
 
@@ -21,8 +26,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define GW_BM 320
 #define GW_BC 64
 #define GW_K 16
-#define GW_ASLOTS (GW_BM * 2)                 // 16-byte slots of one plane of the A tile
-#define GW_XSLOTS (3 * GW_BC * 2)             // ... of the X tile (3 taps)
+#define GW_AQ (GW_BM + 8)                     // slots of one 8-sample half of the A tile (8 pad rows)
+#define GW_XQ (GW_BC + 8)                     // ... of one tap of the X tile
+#define GW_ASLOTS (2 * GW_AQ)                 // 16-byte slots of one plane of the A tile
+#define GW_XSLOTS (3 * 2 * GW_XQ)             // ... of the X tile (3 taps)
 #define GW_BUF (3 * (GW_ASLOTS + GW_XSLOTS))  // slots of one stage buffer (3 planes)
 
 struct GemmNTArgsW {
@@ -115,8 +122,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     sh[0] = 0; sh[1] = 0;
     sh[2] = i2_is_a ? 0 : -a.dil;
     sh[3] = (tap3 - 1) * a.dil;
-    const int slot2 = i2_is_a ? 512 + tid : GW_ASLOTS + (tid - 128);
-    const int slot3 = GW_ASLOTS + 128 + tid;
+    // LDS slot of an item inside a plane: half q = tid & 1, row = (item's first row) + (tid >> 1)
+    const int qh = tid & 1;
+    const int slot0 = qh * GW_AQ + (tid >> 1);
+    const int slot1 = slot0 + 128;
+    const int slot2 = i2_is_a ? slot0 + 256 : GW_ASLOTS + qh * GW_XQ + ((tid - 128) >> 1);
+    const int slot3 = GW_ASLOTS + (tap3 * 2 + qh) * GW_XQ + ((tid & 127) >> 1);
 
     f32x16 acc[MW][3];
 #pragma unroll
@@ -126,8 +137,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[4][2], rb[4][2];                          // two staging register sets (two stages in flight)
+    u32x4 ra[4][2], rb[4][2], rc[4][2];                // three staging register sets (chunks k+1 .. k+3)
 
+    int ld_q = 0;
     int ld_s = (int)(q_begin / cps);
     int ld_c = (int)(q_begin - (long)ld_s * cps);
 
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
                 }                                                                                 \
             }                                                                                     \
         }                                                                                         \
-        if (++ld_c == cps) { ld_c = 0; ++ld_s; }                                                  \
+        if (++ld_q < nst) { if (++ld_c == cps) { ld_c = 0; ++ld_s; } }   /* stays on the last chunk */ \
     }
     // counted wait for register set R_: at most N_ younger load instructions may stay in flight.  (After an
     // edge chunk 32 instead of 8 younger loads are outstanding: vmcnt(8) then over-waits, which is safe.)
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     // splits item I_ of register set R_ into buffer BUF_
 #define GW_STORE(R_, I_, BUF_)                                                                    \
     {                                                                                             \
-        const int slot = (I_) == 0 ? tid : (I_) == 1 ? 256 + tid : (I_) == 2 ? slot2 : slot3;     \
+        const int slot = (I_) == 0 ? slot0 : (I_) == 1 ? slot1 : (I_) == 2 ? slot2 : slot3;       \
         float f_[8];                                                                              \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) f_[r] = __uint_as_float(R_[I_][r >> 2][r & 3]); \
         gw_split_store(f_, lds + (BUF_) * GW_BUF + slot, GW_ASLOTS + GW_XSLOTS);                  \
@@ -179,30 +191,32 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                             \
             acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA_][mt], bf[PB_][j], acc[mt][j], 0, 0, 0);
-    // one stage: MFMAs on buffer BUF_, prefetch into LD_ (if MORE2_), split ST_ into the other buffer (if MORE1_)
-#define GW_STAGE(BUF_, LD_, ST_, MORE2_, MORE1_)                                                  \
+    // one stage k: MFMAs on LDS buffer BUF_; chunk k + 1 (register set ST_) is split into buffer NBUF_; chunk
+    // k + 3 is fetched into register set LD_ (which held chunk k).  Every stage does all of it, the last ones
+    // on clamped (repeated) chunks whose results are never read.
+#define GW_STAGE(BUF_, NBUF_, LD_, ST_)                                                           \
     {                                                                                             \
         const u32x4* pb = lds + (BUF_) * GW_BUF;                                                  \
-        const u32x4* ab = pb + (wm * (MW * 32) + nl) * 2 + h;                                     \
-        const u32x4* xb = pb + GW_ASLOTS + (wc * 32 + nl) * 2 + h;                                \
+        const u32x4* ab = pb + h * GW_AQ + wm * (MW * 32) + nl;                                   \
+        const u32x4* xb = pb + GW_ASLOTS + h * GW_XQ + wc * 32 + nl;                              \
         constexpr int PS = GW_ASLOTS + GW_XSLOTS;                                                 \
         bf16x8 af[3][MW], bf[3][3];                                                               \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[0][j] = __builtin_bit_cast(bf16x8, xb[0 * PS + j * GW_BC * 2]); \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[2][mt] = __builtin_bit_cast(bf16x8, ab[2 * PS + mt * 64]); \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[2][j] = __builtin_bit_cast(bf16x8, xb[2 * PS + j * GW_BC * 2]); \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(bf16x8, ab[0 * PS + mt * 64]); \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[1][j] = __builtin_bit_cast(bf16x8, xb[1 * PS + j * GW_BC * 2]); \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(bf16x8, ab[1 * PS + mt * 64]); \
-        if (MORE2_) GW_LOAD(LD_)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[0][j] = __builtin_bit_cast(bf16x8, xb[0 * PS + j * 2 * GW_XQ]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[2][mt] = __builtin_bit_cast(bf16x8, ab[2 * PS + mt * 32]); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[2][j] = __builtin_bit_cast(bf16x8, xb[2 * PS + j * 2 * GW_XQ]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(bf16x8, ab[0 * PS + mt * 32]); \
         GW_TERM(2, 0)                                                                             \
-        if (MORE1_) { if (MORE2_) GW_WAIT(ST_, 8) else GW_WAIT(ST_, 0) }                          \
-        if (MORE1_) GW_STORE(ST_, 0, (BUF_) ^ 1)                                                  \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[1][j] = __builtin_bit_cast(bf16x8, xb[1 * PS + j * 2 * GW_XQ]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(bf16x8, ab[1 * PS + mt * 32]); \
+        GW_WAIT(ST_, 8)               /* chunk k + 1 landed; the 8 loads of chunk k + 2 may stay in flight */ \
+        GW_STORE(ST_, 0, NBUF_)                                                                   \
         GW_TERM(0, 2)                                                                             \
-        if (MORE1_) GW_STORE(ST_, 1, (BUF_) ^ 1)                                                  \
+        GW_LOAD(LD_)                                                                              \
+        GW_STORE(ST_, 1, NBUF_)                                                                   \
         GW_TERM(1, 1)                                                                             \
-        if (MORE1_) GW_STORE(ST_, 2, (BUF_) ^ 1)                                                  \
+        GW_STORE(ST_, 2, NBUF_)                                                                   \
         GW_TERM(1, 0)                                                                             \
-        if (MORE1_) GW_STORE(ST_, 3, (BUF_) ^ 1)                                                  \
+        GW_STORE(ST_, 3, NBUF_)                                                                   \
         GW_TERM(0, 1)                                                                             \
         GW_TERM(0, 0)                                                                             \
         /* spread the split arithmetic between the MFMAs: one MFMA, then up to three VALU ops */  \
@@ -215,21 +229,19 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
 
     if (nst > 0) {
         GW_LOAD(ra)
-        if (nst > 1) GW_LOAD(rb)
+        GW_LOAD(rb)
+        GW_LOAD(rc)
         GW_WAIT(ra, 0)
-        if (nst > 1) GW_WAIT(rb, 0)
+        GW_WAIT(rb, 0)
+        GW_WAIT(rc, 0)
         GW_STORE(ra, 0, 0) GW_STORE(ra, 1, 0) GW_STORE(ra, 2, 0) GW_STORE(ra, 3, 0)
         __syncthreads();
-        // stage k: MFMAs on buffer k & 1, chunk k + 1 (registers) -> buffer (k + 1) & 1, chunk k + 2 -> registers
-        int k = 0;
-        for (; k + 3 < nst; k += 2) {                  // steady state: no branches inside a stage
-            GW_STAGE(0, ra, rb, true, true)
-            GW_STAGE(1, rb, ra, true, true)
+        // stage k reads buffer k % 3; register set k % 3 held chunk k and now receives chunk k + 3
+        for (int k = 0; k < nst; k += 3) {
+            GW_STAGE(0, 1, ra, rb)
+            if (k + 1 < nst) GW_STAGE(1, 2, rb, rc)
+            if (k + 2 < nst) GW_STAGE(2, 0, rc, ra)
         }
-        // last one to three stages (k is even)
-        GW_STAGE(0, ra, rb, k + 2 < nst, k + 1 < nst)
-        if (k + 1 < nst) GW_STAGE(1, rb, ra, false, k + 2 < nst)
-        if (k + 2 < nst) GW_STAGE(0, ra, rb, false, false)
     }
 #undef GW_LOAD
 #undef GW_WAIT
@@ -292,7 +304,7 @@ int bm_gemm_nt_x3w_try(const float* a, long a_sstride, long a_rstride, const flo
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride;
     g.part = part; g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit;
     g.tiles_m = M / GW_BM; g.tiles_c = Cn / GW_BC;
-    const size_t lds = (size_t)2 * GW_BUF * 16;
+    const size_t lds = (size_t)3 * GW_BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x3w_kernel),
