@@ -57,9 +57,16 @@ __device__ __forceinline__ i32x4 gw_rsrc(const float* p, int bytes) {
 // would drain the queue (vmcnt(0)) at the first use of the older register set and so stall every stage on
 // the loads it has just issued.  The matching counted waits are GW_WAIT below; until then the destination
 // registers must not be read (they are only read by the split that follows the wait).
-__device__ __forceinline__ u32x4 gw_ld128(i32x4 rs, int voff) {
+// interior chunks: per-thread byte offset (constant for the whole kernel) + wave-uniform byte offset of the
+// chunk in an SGPR + 0 / 16 as immediate: no address arithmetic per load
+__device__ __forceinline__ u32x4 gw_ld128(i32x4 rs, int voff, int soff) {
     u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x4 gw_ld128_16(i32x4 rs, int voff, int soff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
     return v;
 }
 __device__ __forceinline__ unsigned gw_ld32(i32x4 rs, int voff) {
@@ -139,9 +146,23 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
 
     u32x4 ra[4][2], rb[4][2], rc[4][2];                // three staging register sets (chunks k+1 .. k+3)
 
+#ifdef GW_PROFILE
+    long long pt[4] = {0, 0, 0, 0};
+    long long plast = clock64();
+    const long long pstart = plast;
+#define GW_PSTAMP(I_) { const long long now_ = clock64(); pt[I_] += now_ - plast; plast = now_; }
+#else
+#define GW_PSTAMP(I_)
+#endif
     int ld_q = 0;
     int ld_s = (int)(q_begin / cps);
     int ld_c = (int)(q_begin - (long)ld_s * cps);
+    int offb[4];                                       // byte offset of the item inside a segment, without the tap
+#pragma unroll                                         // shift (>= 0: a negative voffset would be out of range)
+    for (int i = 0; i < 4; ++i) offb[i] = off[i] * 4;
+    // segment descriptors, rebuilt only when the cursor enters a new segment
+    i32x4 qa = gw_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);
+    i32x4 qx = gw_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);
 
     // loads chunk (ld_s, ld_c) into register set R_ and advances the cursor.  Interior chunks: two dwordx4
     // per item.  Edge chunks (first / last of a segment, wave-uniform): one dword per sample, samples whose
@@ -149,15 +170,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
 #define GW_LOAD(R_)                                                                               \
     {                                                                                             \
         const int t0 = ld_c * GW_K;                                                               \
-        const i32x4 qa = gw_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                        \
-        const i32x4 qx = gw_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                        \
         const i32x4 q2 = i2_is_a ? qa : qx;                                                       \
         if (!(t0 - halo < 0 || t0 + GW_K + halo > a.T)) {                                         \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
                 const i32x4 rs = i < 2 ? qa : i == 2 ? q2 : qx;                                   \
-                const int o = (off[i] + t0 + sh[i]) * 4;                                          \
-                R_[i][0] = gw_ld128(rs, o);                                                       \
-                R_[i][1] = gw_ld128(rs, o + 16);                                                  \
+                const int so = __builtin_amdgcn_readfirstlane((t0 + sh[i]) * 4);   /* >= 0 in interior chunks */ \
+                R_[i][0] = gw_ld128(rs, offb[i], so);                                             \
+                R_[i][1] = gw_ld128_16(rs, offb[i], so);                                          \
             }                                                                                     \
         } else {                                                                                  \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
@@ -171,7 +190,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
                 }                                                                                 \
             }                                                                                     \
         }                                                                                         \
-        if (++ld_q < nst) { if (++ld_c == cps) { ld_c = 0; ++ld_s; } }   /* stays on the last chunk */ \
+        if (++ld_q < nst) {                            /* else: stays on the last chunk */        \
+            if (++ld_c == cps) {                                                                  \
+                ld_c = 0; ++ld_s;                                                                 \
+                qa = gw_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                            \
+                qx = gw_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                            \
+            }                                                                                     \
+        }                                                                                         \
     }
     // counted wait for register set R_: at most N_ younger load instructions may stay in flight.  (After an
     // edge chunk 32 instead of 8 younger loads are outstanding: vmcnt(8) then over-waits, which is safe.)
@@ -191,40 +216,58 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
         _Pragma("unroll") for (int j = 0; j < 3; ++j)                                             \
             acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA_][mt], bf[PB_][j], acc[mt][j], 0, 0, 0);
-    // one stage k: MFMAs on LDS buffer BUF_; chunk k + 1 (register set ST_) is split into buffer NBUF_; chunk
-    // k + 3 is fetched into register set LD_ (which held chunk k).  Every stage does all of it, the last ones
-    // on clamped (repeated) chunks whose results are never read.
+    // Operand fragments live across stages: [plane 0 = hi, 1 = mid, 2 = lo].
+    bf16x8 af[3][MW], bf[3][3];
+    // fragments a stage needs first (B.hi, A.lo, B.lo), read from buffer BUF_ as soon as it is complete
+#define GW_FRAGS_EARLY(BUF_)                                                                      \
+    {                                                                                             \
+        const u32x4* pb = lds + (BUF_) * GW_BUF;                                                  \
+        const u32x4* ab = pb + h * GW_AQ + wm * (MW * 32) + nl;                                   \
+        const u32x4* xb = pb + GW_ASLOTS + h * GW_XQ + wc * 32 + nl;                              \
+        constexpr int PS = GW_ASLOTS + GW_XSLOTS;                                                 \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[0][j] = __builtin_bit_cast(bf16x8, xb[0 * PS + j * 2 * GW_XQ]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[2][mt] = __builtin_bit_cast(bf16x8, ab[2 * PS + mt * 32]); \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[2][j] = __builtin_bit_cast(bf16x8, xb[2 * PS + j * 2 * GW_XQ]); \
+    }
+    // One stage k.  On entry B.hi, A.lo, B.lo of buffer BUF_ are already in registers (read right after the
+    // barrier of stage k - 1, under its last 30 MFMAs).  Chunk k + 1 (register set ST_) is split into buffer
+    // NBUF_ between the first 60 MFMAs (lo*hi, hi*lo, mid*hi, hi*hi); chunk k + 3 is fetched into register set
+    // LD_ (which held chunk k); then the barrier, the early fragments of stage k + 1, and the last 30 MFMAs
+    // (mid*mid, hi*mid).  Every stage does all of it, the last ones on clamped (repeated) chunks whose
+    // results are never read.  The order of the six partial products inside a stage is immaterial for the
+    // rounding: each is added to the running fp32 sum over all earlier stages.
 #define GW_STAGE(BUF_, NBUF_, LD_, ST_)                                                           \
     {                                                                                             \
         const u32x4* pb = lds + (BUF_) * GW_BUF;                                                  \
         const u32x4* ab = pb + h * GW_AQ + wm * (MW * 32) + nl;                                   \
         const u32x4* xb = pb + GW_ASLOTS + h * GW_XQ + wc * 32 + nl;                              \
         constexpr int PS = GW_ASLOTS + GW_XSLOTS;                                                 \
-        bf16x8 af[3][MW], bf[3][3];                                                               \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[0][j] = __builtin_bit_cast(bf16x8, xb[0 * PS + j * 2 * GW_XQ]); \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[2][mt] = __builtin_bit_cast(bf16x8, ab[2 * PS + mt * 32]); \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[2][j] = __builtin_bit_cast(bf16x8, xb[2 * PS + j * 2 * GW_XQ]); \
         _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(bf16x8, ab[0 * PS + mt * 32]); \
+        GW_WAIT(ST_, 8)               /* chunk k + 1 landed; the 8 loads of chunk k + 2 may stay in flight */ \
+        GW_STORE(ST_, 0, NBUF_)                                                                   \
         GW_TERM(2, 0)                                                                             \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[1][j] = __builtin_bit_cast(bf16x8, xb[1 * PS + j * 2 * GW_XQ]); \
         _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(bf16x8, ab[1 * PS + mt * 32]); \
-        GW_WAIT(ST_, 8)               /* chunk k + 1 landed; the 8 loads of chunk k + 2 may stay in flight */ \
-        GW_STORE(ST_, 0, NBUF_)                                                                   \
-        GW_TERM(0, 2)                                                                             \
-        GW_LOAD(LD_)                                                                              \
         GW_STORE(ST_, 1, NBUF_)                                                                   \
-        GW_TERM(1, 1)                                                                             \
+        GW_TERM(0, 2)                                                                             \
         GW_STORE(ST_, 2, NBUF_)                                                                   \
         GW_TERM(1, 0)                                                                             \
         GW_STORE(ST_, 3, NBUF_)                                                                   \
-        GW_TERM(0, 1)                                                                             \
         GW_TERM(0, 0)                                                                             \
-        /* spread the split arithmetic between the MFMAs: one MFMA, then up to three VALU ops */  \
-        _Pragma("unroll") for (int g_ = 0; g_ < 75; ++g_) {                                       \
+        /* spread the split arithmetic between the MFMAs: one MFMA, then up to three VALU ops (a VALU */ \
+        /* op holds the issue port for 8 cycles, an MFMA for 8 of its 32: scripts/micro/mfma_valu_mix.hip) */ \
+        _Pragma("unroll") for (int g_ = 0; g_ < 60; ++g_) {                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
         }                                                                                         \
+        GW_PSTAMP(0)                                                                              \
         __syncthreads();                                                                          \
+        GW_PSTAMP(1)                                                                              \
+        GW_FRAGS_EARLY(NBUF_)                                                                     \
+        GW_LOAD(LD_)                                                                              \
+        GW_TERM(1, 1)                                                                             \
+        GW_TERM(0, 1)                                                                             \
+        GW_PSTAMP(2)                                                                              \
     }
 
     if (nst > 0) {
@@ -236,19 +279,29 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
         GW_WAIT(rc, 0)
         GW_STORE(ra, 0, 0) GW_STORE(ra, 1, 0) GW_STORE(ra, 2, 0) GW_STORE(ra, 3, 0)
         __syncthreads();
+        GW_FRAGS_EARLY(0)
         // stage k reads buffer k % 3; register set k % 3 held chunk k and now receives chunk k + 3
         for (int k = 0; k < nst; k += 3) {
             GW_STAGE(0, 1, ra, rb)
             if (k + 1 < nst) GW_STAGE(1, 2, rb, rc)
             if (k + 2 < nst) GW_STAGE(2, 0, rc, ra)
         }
+        // The compiler does not know about the asm-issued fetches: the (unused) ones of the last stages are
+        // still in flight and would land in registers it hands to the epilogue.  Drain them here.
+        GW_WAIT(ra, 0)
+        GW_WAIT(rb, 0)
+        GW_WAIT(rc, 0)
     }
 #undef GW_LOAD
+#undef GW_FRAGS_EARLY
 #undef GW_WAIT
 #undef GW_STORE
 #undef GW_TERM
 #undef GW_STAGE
 
+#ifdef GW_PROFILE
+    const long long ptotal = clock64() - pstart;
+#endif
     // partial tile out: part[split][m][c * 3 + j]
     const long N = (long)a.Cn * 3;
     float* dst = a.part + (long)split * a.M * N;
@@ -266,6 +319,15 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
             }
         }
     }
+#ifdef GW_PROFILE
+    __syncthreads();
+    if (blockIdx.x == 0 && lane == 0) {     // overwrites the head of the partial buffer: profiling builds only
+        float* d = a.part + wave * 8;
+        for (int i = 0; i < 4; ++i) d[i] = (float)(pt[i] / nst);
+        d[4] = (float)(ptotal / nst);
+        d[5] = (float)nst;
+    }
+#endif
 }
 
 static bool gw_covers(int S, int G, int M, int Cn, int T, int KS, int dil, bool ordered) {

@@ -182,3 +182,21 @@ def test_data_parallel_exchange_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"WORKER_OK {r}" in out, out
+
+
+def test_wide_kernels_do_not_spill(tmp_path):
+    """gemm_nt_x3w issues its staging loads through inline asm with hand-counted waits: a register the
+    compiler spilled (or re-used) while such a load is in flight would be silently corrupted, so the wide
+    kernels must compile without VGPR spills."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    csrc = ROOT / "brainmagick_amd" / "csrc"
+    for name in ("gemm_nt_x3w.hip", "conv_nn_x3w.hip"):
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        f"-I{csrc}", "-o", str(out), str(csrc / name)], check=True, capture_output=True)
+        spills = [int(l.split(":")[1]) for l in out.read_text().splitlines() if ".vgpr_spill_count" in l]
+        assert spills and all(s == 0 for s in spills), (name, spills)
