@@ -10,8 +10,10 @@
 // next chunk travels through registers (it has to be split into the three bf16 planes).
 //
 // Packed weights are those of bm_pack_weights_x3 ([g][chunk32][tap][plane][4 groups][Mpad] 16-byte slots);
-// a stage uses two of the four 8-channel groups.  LDS: A [2 buffers][plane][2 groups][320 rows],
-// X [2 buffers][plane][2 groups][224 columns], 102 KB.
+// a stage uses two of the four 8-channel groups.  LDS: A [3 buffers][plane][2 groups][320 rows],
+// X [2 buffers][plane][2 groups][256 columns], 141 KB.  The slab of stage s + 2 is requested at the start
+// of stage s; the barrier of a stage sits before its last 30 MFMAs, and the first fragments of the next
+// stage are read under them.
 #include <cstdlib>
 #include "conv_common.h"
 
@@ -39,27 +41,25 @@ __device__ __forceinline__ void split8w(const float* f, u32x4& hi, u32x4& mid, u
     lo = __builtin_bit_cast(u32x4, l);
 }
 
-#ifdef WIDE_NO_X
-#define WIDE_XLOAD(OFF_) (float)((OFF_) & 3)
-#else
-#define WIDE_XLOAD(OFF_) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (OFF_), 0, 0))
-#endif
-#ifdef WIDE_NO_DMA
-#define WIDE_COPY(SRC_, DST_) (DST_)[lane] = *(SRC_);
-#else
-#define WIDE_COPY(SRC_, DST_)                                                                     \
-    __builtin_amdgcn_global_load_lds((const void*)(SRC_), (__attribute__((address_space(3))) void*)(DST_), 16, 0, 0);
-#endif
+typedef int i32x4w __attribute__((ext_vector_type(4)));
+
+// The input-window loads of the main loop are issued through inline asm and the barriers are raw s_barrier
+// with hand-counted waits: __syncthreads() would drain the VMEM queue (vmcnt(0)), i.e. wait for the weight
+// slab that has just been requested two stages ahead.  Rules that keep this safe: no value produced by the
+// asm loads is read before the matching CW_WAIT_X; the kernel compiles without spills in the main loop
+// (tests/test_host_cpu.py); everything is drained before the epilogue.
+__device__ __forceinline__ float cw_ld32(i32x4w rs, int voff) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
 
 template <int KS>
 __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
     constexpr int MW = 5, NW = 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    u32x4* As = reinterpret_cast<u32x4*>(smem);       // [2][3][2][WBM]
-    u32x4* Xs = As + 2 * WASLAB;                      // [2][3][2][WXWP]
-#ifdef WIDE_PROFILE
-    const long long pentry = clock64();
-#endif
+    u32x4* As = reinterpret_cast<u32x4*>(smem);       // [3 buffers][3 planes][2 groups][WBM]
+    u32x4* Xs = As + 3 * WASLAB;                      // [2 buffers][3 planes][2 groups][WXWP]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,17 +79,18 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
 
     const int g = a.widx ? a.widx[b] : 0;
     const int nchunk32 = a.nchunk;
-    const int n16 = (a.Cin + 15) >> 4;
+    const int n16 = a.Cin >> 4;                       // Cin % 16 == 0 (eligibility)
     const int nstage = n16 * KS;
     // packed weights in 16-byte slots: [g][chunk32][tap][plane][4][Mpad]
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (long)g * nchunk32 * KS * 12 * a.Mpad + m0 + lane;
 
-    // input window of this segment through a bounds-checked buffer descriptor: channels past Cin read 0
+    // input window of this segment through a bounds-checked buffer descriptor
     const unsigned long long xaddr = (unsigned long long)(a.x + (long)b * a.x_bstride);
-    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xaddr);          // (readfirstlane returns int:
-    const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xaddr >> 32));  //  keep the halves unsigned)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(((unsigned long long)xhi << 32) | xlo), 0, __builtin_amdgcn_readfirstlane(a.Cin * a.T * 4), 0x00020000);
+    i32x4w xr;
+    xr[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xaddr);
+    xr[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xaddr >> 32) & 0xffffu));
+    xr[2] = __builtin_amdgcn_readfirstlane(a.Cin * a.T * 4);
+    xr[3] = 0x00020000;
     // thread `tid` stages window column tid (both 8-channel groups); columns outside [0, T) or past the
     // window get an offset that stays out of range for every channel -> they read as 0 (conv zero padding)
     const int tcol = n0 - halo + tid;
@@ -105,28 +106,36 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
     float xreg[16];
+    bf16x8 af[3][MW], bf[3][NW];                      // operand fragments [plane 0 = hi, 1 = mid, 2 = lo]
 
-    // DMA of the A slab of stage S_ into buffer (S_ & 1): 30 copies of 64 rows x 16 B, wavefront w
-    // issues copies w, w + 4, ...
-#define DMA_A(S_)                                                                                 \
+
+    // DMA of the A slab of stage S_ (clamped to the last stage) into A buffer S_ % 3
+#define DMA_A(S_, BUF3_)                                                                          \
     {                                                                                             \
-        const int c16 = (S_) / KS, jj = (S_) - c16 * KS;                                          \
+        const int sc = (S_) < nstage ? (S_) : nstage - 1;                                         \
+        const int c16 = sc / KS, jj = sc - c16 * KS;                                              \
         const u32x4* src = wg + ((long)((c16 >> 1) * KS + jj) * 12 + (c16 & 1) * 2) * a.Mpad;     \
-        u32x4* dstb = As + ((S_) & 1) * WASLAB;                                                   \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
             int k = wave + 4 * i;                                                                 \
-            k = k < 30 ? k : k - 4;      /* wavefronts 2, 3 repeat their last copy: no branch */  \
+            k = k < 30 ? k : k - 4;                                                               \
             const int run = k / 5, rb = k - run * 5;            /* run = plane * 2 + group */     \
             const int plane = run >> 1, kg = run & 1;                                             \
-            WIDE_COPY((src + (long)(plane * 4 + kg) * a.Mpad + rb * 64), (dstb + run * WBM + rb * 64)) \
+            __builtin_amdgcn_global_load_lds(                                                     \
+                (const void*)(src + (long)(plane * 4 + kg) * a.Mpad + rb * 64),                   \
+                (__attribute__((address_space(3))) void*)(As + (BUF3_) * WASLAB + run * WBM + rb * 64), 16, 0, 0); \
         }                                                                                         \
     }
+    // 16 channels x 1 column of the input window of chunk C16_ (zeros past the last chunk: offset out of range)
 #define LOAD_X(C16_)                                                                              \
     {                                                                                             \
         const int cb = (C16_) * 16 * crow + xoff0;                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                            \
-            xreg[r] = WIDE_XLOAD(cb + r * crow);                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) xreg[r] = cw_ld32(xr, cb + r * crow);      \
     }
+#define CW_WAIT_X(N_)                                                                             \
+    asm volatile("s_waitcnt vmcnt(" #N_ ")"                                                       \
+                 : "+v"(xreg[0]), "+v"(xreg[1]), "+v"(xreg[2]), "+v"(xreg[3]), "+v"(xreg[4]), "+v"(xreg[5]),  \
+                   "+v"(xreg[6]), "+v"(xreg[7]), "+v"(xreg[8]), "+v"(xreg[9]), "+v"(xreg[10]), "+v"(xreg[11]), \
+                   "+v"(xreg[12]), "+v"(xreg[13]), "+v"(xreg[14]), "+v"(xreg[15])::"memory");
 #define STORE_X(BUF_)                                                                             \
     {                                                                                             \
         u32x4* xd = Xs + (BUF_) * WXSLAB + tid;                                                   \
@@ -138,79 +147,83 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
             xd[(2 * 2 + kg) * WXWP] = lo;                                                         \
         }                                                                                         \
     }
-
-    DMA_A(0);
-    LOAD_X(0);
-    STORE_X(0);
-    __syncthreads();
-
-#ifdef WIDE_PROFILE
-    long long pt[5] = {0, 0, 0, 0, 0};
-#define PSTAMP(I_) { const long long now_ = clock64(); pt[I_] += now_ - plast; plast = now_; }
-    long long plast = clock64();
-    const long long pc0 = plast, pw0 = wall_clock64();
-#else
-#define PSTAMP(I_)
-#endif
-    int s = 0;
-    for (int c16 = 0; c16 < n16; ++c16) {
-#pragma unroll
-        for (int j = 0; j < KS; ++j, ++s) {
-            // next stage's weight slab by DMA first: it has the whole stage to land (the last stage re-copies
-            // its own slab: no branches inside a stage)
-#ifndef WIDE_EXP_NODMA
-            DMA_A(s + 1 < nstage ? s + 1 : s);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            // this stage's operand fragments, in the order the partial products consume them
-            const u32x4* ab = As + (s & 1) * WASLAB + h * WBM + wm * (MW * 32) + nl;
-            const u32x4* xb = Xs + (c16 & 1) * WXSLAB + h * WXWP + wn * (NW * 32) + nl + j * a.dil;
-            bf16x8 af[3][MW], bf[3][NW];
-#define FRAGS(PA_, PB_)                                                                           \
-    _Pragma("unroll") for (int nt = 0; nt < NW; ++nt)                                             \
-        bf[PB_][nt] = __builtin_bit_cast(bf16x8, xb[(PB_) * 2 * WXWP + nt * 32]);                 \
-    _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
-        af[PA_][mt] = __builtin_bit_cast(bf16x8, ab[(PA_) * 2 * WBM + mt * 32]);
-            FRAGS(2, 0) FRAGS(0, 2) FRAGS(1, 1)
-#undef FRAGS
-#ifndef WIDE_EXP_NOX
-            if (j == 0) LOAD_X(c16 + 1);   // next chunk's input window into registers (zeros past the last chunk)
-#endif
-            PSTAMP(0)
-#ifdef WIDE_PROFILE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            PSTAMP(1)
-#ifndef WIDE_EXP_NOX
-            if (j == KS - 1) STORE_X((c16 + 1) & 1);
-#endif
-            // six partial products, smallest first (planes: 0 = hi, 1 = mid, 2 = lo)
+    // fragments a stage needs first (B.hi, A.lo, B.lo); ABUF_ = its A buffer, XB_/J_ = its X buffer and tap
+#define FRAGS_EARLY(ABUF_, XB_, J_)                                                               \
+    {                                                                                             \
+        const u32x4* ab = As + (ABUF_) * WASLAB + h * WBM + wm * (MW * 32) + nl;                  \
+        const u32x4* xb = Xs + (XB_) * WXSLAB + h * WXWP + wn * (NW * 32) + nl + (J_) * a.dil;    \
+        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[0][nt] = __builtin_bit_cast(bf16x8, xb[0 * 2 * WXWP + nt * 32]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[2][mt] = __builtin_bit_cast(bf16x8, ab[2 * 2 * WBM + mt * 32]); \
+        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[2][nt] = __builtin_bit_cast(bf16x8, xb[2 * 2 * WXWP + nt * 32]); \
+    }
+#define FRAGS_LATE(ABUF_, XB_, J_)                                                                \
+    {                                                                                             \
+        const u32x4* ab = As + (ABUF_) * WASLAB + h * WBM + wm * (MW * 32) + nl;                  \
+        const u32x4* xb = Xs + (XB_) * WXSLAB + h * WXWP + wn * (NW * 32) + nl + (J_) * a.dil;    \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(bf16x8, ab[0 * 2 * WBM + mt * 32]); \
+        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[1][nt] = __builtin_bit_cast(bf16x8, xb[1 * 2 * WXWP + nt * 32]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(bf16x8, ab[1 * 2 * WBM + mt * 32]); \
+    }
 #define TERM(PA_, PB_)                                                                            \
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
         _Pragma("unroll") for (int nt = 0; nt < NW; ++nt)                                         \
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA_][mt], bf[PB_][nt], acc[mt][nt], 0, 0, 0);
-            TERM(2, 0) TERM(0, 2) TERM(1, 1) TERM(1, 0) TERM(0, 1) TERM(0, 0)
-#undef TERM
-            PSTAMP(2)
-            PSTAMP(3)
-#ifndef WIDE_EXP_NOBARRIER
-            __syncthreads();      // next A slab landed (vmcnt) and visible, this stage's LDS reads are done
-#endif
-            PSTAMP(4)
+    // "slab s + 1 landed" + workgroup barrier: N_ younger VMEM instructions may stay in flight
+#define CW_BARRIER(N_)                                                                            \
+    asm volatile("s_waitcnt vmcnt(" #N_ ") lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // prologue: slabs 0 and 1, input window of chunk 0
+    DMA_A(0, 0)
+    DMA_A(1, 1)
+    LOAD_X(0)
+    CW_WAIT_X(0)
+    STORE_X(0)
+    CW_BARRIER(0)
+    FRAGS_EARLY(0, 0, 0)
+
+    // Stage s = (16-channel chunk c16, tap j), A buffer s % 3, X buffer c16 & 1.  VMEM queue order inside a
+    // stage: [input window of chunk c16 + 1, 16 loads, if j == 0], slab s + 2 (8 DMA copies).  Before the
+    // barrier slab s + 1 must have landed: younger than it are 8 (+ 16 if j == 0) instructions.  The input
+    // window is consumed in the stage with j == KS - 1: younger than it are the KS slabs issued since.
+    int s = 0;
+    int ab3 = 0;                                      // s % 3
+    for (int c16 = 0; c16 < n16; ++c16) {
+        const int xbuf = c16 & 1;
+#pragma unroll
+        for (int j = 0; j < KS; ++j, ++s) {
+            const int ab_next = ab3 == 2 ? 0 : ab3 + 1;
+            const int ab_next2 = ab_next == 2 ? 0 : ab_next + 1;
+            if (j == 0) LOAD_X(c16 + 1)
+            DMA_A(s + 2, ab_next2)
+            FRAGS_LATE(ab3, xbuf, j)
+            if (j == KS - 1) {
+                if (KS == 3) CW_WAIT_X(24) else CW_WAIT_X(8)
+                STORE_X(xbuf ^ 1)
+            }
+            TERM(2, 0) TERM(0, 2) TERM(1, 0) TERM(0, 0)
+            if (j == KS - 1) {       // spread the split arithmetic of the input window between the MFMAs
+                _Pragma("unroll") for (int g_ = 0; g_ < 45; ++g_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+            }
+            if (j == 0) CW_BARRIER(24) else CW_BARRIER(8)
+            if (j == KS - 1) FRAGS_EARLY(ab_next, xbuf ^ 1, 0) else FRAGS_EARLY(ab_next, xbuf, j + 1)
+            TERM(1, 1) TERM(0, 1)
+            ab3 = ab_next;
         }
     }
+    // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #undef DMA_A
 #undef LOAD_X
+#undef CW_WAIT_X
 #undef STORE_X
+#undef FRAGS_EARLY
+#undef FRAGS_LATE
+#undef TERM
+#undef CW_BARRIER
 
-#ifdef WIDE_PROFILE
-    if (a.stats && blockIdx.x == 0 && lane == 0) {
-        for (int i = 0; i < 5; ++i) a.stats[wave * 8 + i] = (float)pt[i] / (float)nstage;
-        a.stats[wave * 8 + 5] = (float)(clock64() - pc0);
-        a.stats[wave * 8 + 6] = (float)(wall_clock64() - pw0);
-        a.stats[wave * 8 + 7] = (float)(pc0 - pentry);
-    }
-#endif
     // epilogue: bias, optional pre-activation store, per-channel affine, activation, residual.
     // One literal-indexed expansion per accumulator block keeps the 240 accumulators in registers.
     float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
@@ -223,22 +236,14 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
                             n0 + wn * (NW * 32) + (NT_) * 32 + nl, v_);                           \
     }
 #define EPI_ROW(MT_) EPI(MT_, 0) EPI(MT_, 1) EPI(MT_, 2)
-#ifdef WIDE_NO_EPI
-    if (a.y_pre && tid == 0 && blockIdx.x == 0) a.y_pre[0] = acc[0][0][0] + acc[4][2][15] + acc[2][1][7];
-#else
     EPI_ROW(0) EPI_ROW(1) EPI_ROW(2) EPI_ROW(3) EPI_ROW(4)
-#endif
 #undef EPI_ROW
 #undef EPI
-#ifdef WIDE_PROFILE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a.stats && blockIdx.x == 0 && lane == 0) a.stats[32 + wave] = (float)(clock64() - pentry);
-#endif
 }
 
 template <int KS>
 static int launch_conv_nn_x3w(ConvNNArgs a, hipStream_t stream) {
-    const size_t lds = (size_t)(2 * WASLAB + 2 * WXSLAB) * 16;
+    const size_t lds = (size_t)(3 * WASLAB + 2 * WXSLAB) * 16;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_x3w_kernel<KS>),
@@ -264,11 +269,9 @@ static int x3w_enabled() {
 }
 
 static bool x3w_covers(int Cin, int Mpad, int T, int KS, int dil, bool with_stats) {
-#ifndef WIDE_PROFILE
     if (with_stats) return false;
-#endif
     if (!x3w_enabled() || Mpad % WBM != 0 || (KS != 1 && KS != 3)) return false;
-    if ((KS >> 1) * dil > 16 || T <= 128) return false;
+    if ((KS >> 1) * dil > 16 || T <= 128 || Cin % 16 != 0) return false;
     return (long)Cin * T * 4 < 0x40000000L;
 }
 
