@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--negatives", default=None, choices=["local", "node"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true",
+                    help="skip the extra exact-fp32 MFMA timing block (profiling runs)")
     ap.add_argument("--dtype", default="f32x3", choices=["f32x3", "f32", "bf16"],
                     help="compute mode of the contractions. f32x3 (default): fp32-accurate 3xbf16-split "
                          "emulation on the bf16 matrix cores (same parity tolerances as exact fp32); f32: "
@@ -158,7 +160,7 @@ def main():
 
     # For transparency the same job is also timed in the exact-fp32 MFMA mode (not part of `value`).
     exact = None
-    if args.dtype == "f32x3":
+    if args.dtype == "f32x3" and not args.no_exact:
         hip_ops.set_compute_dtype("f32")
         k2 = max(2, args.steps // 4)
         solver.train_step(batch)
