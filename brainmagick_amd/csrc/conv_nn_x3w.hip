@@ -79,12 +79,12 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
 
     const int g = a.widx ? a.widx[b] : 0;
     const int nchunk32 = a.nchunk;
-    const int n16 = a.Cin >> 4;                       // Cin % 16 == 0 (eligibility)
+    const int n16 = (a.Cin + 15) >> 4;                // channels past Cin read 0 through the bounds check
     const int nstage = n16 * KS;
     // packed weights in 16-byte slots: [g][chunk32][tap][plane][4][Mpad]
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (long)g * nchunk32 * KS * 12 * a.Mpad + m0 + lane;
 
-    // input window of this segment through a bounds-checked buffer descriptor
+    // input window of this segment through a bounds-checked buffer descriptor: channels past Cin read 0
     const unsigned long long xaddr = (unsigned long long)(a.x + (long)b * a.x_bstride);
     i32x4w xr;
     xr[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xaddr);
@@ -271,7 +271,7 @@ static int x3w_enabled() {
 static bool x3w_covers(int Cin, int Mpad, int T, int KS, int dil, bool with_stats) {
     if (with_stats) return false;
     if (!x3w_enabled() || Mpad % WBM != 0 || (KS != 1 && KS != 3)) return false;
-    if ((KS >> 1) * dil > 16 || T <= 128 || Cin % 16 != 0) return false;
+    if ((KS >> 1) * dil > 16 || T <= 128) return false;
     return (long)Cin * T * 4 < 0x40000000L;
 }
 
