@@ -102,6 +102,36 @@ def cpu_baseline(workload, seconds_budget=20.0):
                        f"{med * 1e3:.0f} ms, torch CPU fp32")
 
 
+def retrieval_block(workload, B, steps, dev, n_train=8, n_held=4):
+    """top-k segment retrieval (scripts/run_eval_probs.py:237-264 rule) of the full-size model after `steps`
+    training steps on planted-latent synthetic batches, evaluated on held-out segments of the
+    same synthetic world.  Chance level for top-10 is 10 / (n_held * B)."""
+    from brainmagick_amd import retrieval
+    from brainmagick_amd.losses import ClipLoss
+    c = synthetic.CONFIGS[workload]
+    kw = dict(planted=True)
+    if workload == "cfg5":
+        kw["mixed_eeg"] = True
+    torch.manual_seed(77)
+    model = SimpleConv(in_channels={"meg": c["C"]}, out_channels=c["F"], hidden={"meg": 320},
+                       n_subjects=c["S"], **CLIP_CONV)
+    solver = Solver(model, device=str(dev), negatives="local")
+    train = [synthetic.make_batch(B, c["C"], c["T"], c["F"], c["S"], seed=500 + i, **kw).to(dev)
+             for i in range(n_train)]
+    losses = [float(solver.train_step(train[i % n_train])) for i in range(steps)]
+    ests, cands = [], []
+    for i in range(n_held):
+        held = synthetic.make_batch(B, c["C"], c["T"], c["F"], c["S"], seed=9000 + i, **kw).to(dev)
+        e, o = solver.predict(held)
+        ests.append(e)
+        cands.append(o)
+    acc = retrieval.segment_topk_accuracy(ClipLoss().to(dev), torch.cat(ests), torch.cat(cands), topks=(1, 10))
+    n = n_held * B
+    return {"top1": acc["top1"], "top10": acc["top10"], "chance_top10": 10.0 / n, "held_out_segments": n,
+            "train_steps": steps, "train_batches": n_train, "first_loss": losses[0], "last_loss": losses[-1],
+            "data": "planted-latent synthetic world (brainmagick_amd/synthetic.py), default compute mode"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +141,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--negatives", default=None, choices=["local", "node"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accuracy-steps", type=int, default=60,
+                    help="second half of the metric: after the timed region (never part of `value`), train a fresh "
+                         "model this many steps on planted-signal synthetic batches and report top-1/top-10 "
+                         "segment retrieval on held-out segments (single-GPU runs only; 0 disables)")
     ap.add_argument("--no-exact", action="store_true",
                     help="skip the extra exact-fp32 MFMA timing block (profiling runs)")
     ap.add_argument("--dtype", default="f32x3", choices=["f32x3", "f32", "bf16"],
@@ -223,6 +257,12 @@ def main():
                      / (elapsed / args.steps) if args.workload == "cfg2" else None},
     }
     out["exact_f32_mfma"] = exact
+    out["retrieval"] = None
+    if world == 1 and args.accuracy_steps > 0:
+        try:
+            out["retrieval"] = retrieval_block(args.workload, B, args.accuracy_steps, dev)
+        except Exception as exc:   # the throughput line must survive a failure of the side measurement
+            out["retrieval"] = {"error": repr(exc)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     else:
