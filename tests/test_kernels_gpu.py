@@ -4,6 +4,7 @@ each test (rel-L2 unless stated)."""
 import math
 
 import pytest
+from pathlib import Path
 import torch
 from torch.nn import functional as F
 
@@ -96,7 +97,7 @@ def test_conv_backward_kernels(H, Cin, M, KS, dil, T, B):
     dw = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil)
     assert dw.shape == (1, M, Cin, KS)
     assert rel_l2(dw[0], w.grad) < GRAD_TOL
-    for nsplit in (1, 3, 4):
+    for nsplit in (1, 3, 4, 50):     # 50: one or two 16-sample stages per workgroup in the wide-tile kernel
         dw2 = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil, nsplit=nsplit)
         assert rel_l2(dw2[0], w.grad) < GRAD_TOL
 
@@ -411,3 +412,37 @@ def test_word_level_wer_batched(H, n_neg):
     assert got["wer"] == pytest.approx(ref["wer"], abs=1e-9)
     assert got["wer_vocab"] == pytest.approx(ref["wer_vocab"], abs=1e-9)
     assert 0 < ref["wer"] < 1
+
+
+@pytest.mark.gpu
+def test_wide_and_narrow_f32x3_kernels_agree(tmp_path):
+    """The wide-tile kernels (conv_nn_x3w / gemm_nt_x3w) and the 160x128 / 64x64 ones they replace for the
+    big layers are two implementations of the same fp32-accurate contraction: run the same conv forward,
+    data gradient and weight gradient with BM_X3_WIDE=0 in a second process and compare."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "narrow.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {str(Path(__file__).resolve().parent.parent)!r})\n"
+        "import brainmagick_amd\n"
+        "from brainmagick_amd import hip_ops as H\n"
+        "brainmagick_amd.set_compute_dtype('f32x3')\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "B, Cin, M, KS, dil, T = 5, 320, 640, 3, 4, 361\n"
+        "x = torch.randn(B, Cin, T, generator=g).cuda(); w = (torch.randn(M, Cin, KS, generator=g) / 31).cuda()\n"
+        "dy = torch.randn(B, M, T, generator=g).cuda()\n"
+        "y = H.conv_nn(x, H.pack_conv_fwd(w), M, KS, dil)[1]\n"
+        "dx = H.conv_nn(dy, H.pack_conv_dgrad(w), Cin, KS, dil)[1]\n"
+        "dw = H.gemm_nt(dy, x, B, M, Cin, T, KS, dil)\n"
+        "wide = H.lib().bm_conv_x3_is_wide(Cin, M, T, KS, dil, 0)\n"
+        "torch.save({'y': y.cpu(), 'dx': dx.cpu(), 'dw': dw.cpu(), 'wide': wide}, sys.argv[1])\n")
+    outs = {}
+    for tag, env in (("wide", {}), ("narrow", {"BM_X3_WIDE": "0"})):
+        out = tmp_path / f"{tag}.pt"
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env={**os.environ, **env})
+        outs[tag] = torch.load(out)
+    assert outs["wide"]["wide"] == 1 and outs["narrow"]["wide"] == 0
+    for k in ("y", "dx", "dw"):
+        assert rel_l2(outs["wide"][k], outs["narrow"][k].double()) < 2e-6, k
