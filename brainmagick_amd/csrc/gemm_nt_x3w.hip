@@ -64,30 +64,27 @@ __device__ __forceinline__ u32x4 gw_ld128(i32x4 rs, int voff, int soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
     return v;
 }
-__device__ __forceinline__ u32x4 gw_ld128_16(i32x4 rs, int voff, int soff) {
-    u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-    return v;
-}
 __device__ __forceinline__ unsigned gw_ld32(i32x4 rs, int voff) {
     unsigned v;
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
     return v;
 }
 
-// exact 3-way split of 8 fp32 values into bf16 planes and store into the three plane tiles
-__device__ __forceinline__ void gw_split_store(const float (&f)[8], u32x4* dst, int plane_stride) {
-    bf16x8 h, m, l;
+// exact 3-way split of 4 fp32 values into bf16 planes; one 8-byte store per plane tile
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gw_split_store4(const float (&f)[4], char* dst, int plane_stride_bytes) {
+    bf16x4 h, m, l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const __bf16 a = (__bf16)f[i];
         const float r1 = f[i] - (float)a;
         const __bf16 b = (__bf16)r1;
         h[i] = a; m[i] = b; l[i] = (__bf16)(r1 - (float)b);
     }
-    dst[0] = __builtin_bit_cast(u32x4, h);
-    dst[plane_stride] = __builtin_bit_cast(u32x4, m);
-    dst[2 * plane_stride] = __builtin_bit_cast(u32x4, l);
+    *reinterpret_cast<u32x2*>(dst) = __builtin_bit_cast(u32x2, h);
+    *reinterpret_cast<u32x2*>(dst + plane_stride_bytes) = __builtin_bit_cast(u32x2, m);
+    *reinterpret_cast<u32x2*>(dst + 2 * plane_stride_bytes) = __builtin_bit_cast(u32x2, l);
 }
 
 __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
@@ -115,26 +112,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     const int a_bytes = (int)(((long)(a.M - 1) * a.a_rstride + a.T) * 4);
     const int x_bytes = (int)(((long)(a.Cn - 1) * a.x_rstride + a.T) * 4);
 
-    // the four 8-sample items of this thread.  Items 0, 1: A rows 0..255; item 2: A rows 256..319
-    // (wavefronts 0, 1) or tap 0 of X (wavefronts 2, 3); item 3: taps 1 / 2 of X.  Which operand an item
-    // belongs to is wave-uniform.  LDS slot inside a plane: A -> e, X -> GW_ASLOTS + (e - 640).
-    const bool i2_is_a = wave < 2;
-    const int tap3 = wave < 2 ? 1 : 2;
-    int off[4], sh[4];                                 // element offset inside the segment, tap shift
-    off[0] = (m0 + (tid >> 1)) * (int)a.a_rstride + 8 * (tid & 1);
-    off[1] = (m0 + 128 + (tid >> 1)) * (int)a.a_rstride + 8 * (tid & 1);
-    off[2] = i2_is_a ? (m0 + 256 + (tid >> 1)) * (int)a.a_rstride + 8 * (tid & 1)
-                     : (c0 + ((tid - 128) >> 1)) * (int)a.x_rstride + 8 * (tid & 1);
-    off[3] = (c0 + ((tid & 127) >> 1)) * (int)a.x_rstride + 8 * (tid & 1);
-    sh[0] = 0; sh[1] = 0;
-    sh[2] = i2_is_a ? 0 : -a.dil;
-    sh[3] = (tap3 - 1) * a.dil;
-    // LDS slot of an item inside a plane: half q = tid & 1, row = (item's first row) + (tid >> 1)
-    const int qh = tid & 1;
-    const int slot0 = qh * GW_AQ + (tid >> 1);
-    const int slot1 = slot0 + 128;
-    const int slot2 = i2_is_a ? slot0 + 256 : GW_ASLOTS + qh * GW_XQ + ((tid - 128) >> 1);
-    const int slot3 = GW_ASLOTS + (tap3 * 2 + qh) * GW_XQ + ((tid & 127) >> 1);
+    // The eight 4-sample pieces of this thread: lane -> (row64 = tid >> 2, quarter p = tid & 3 of the 16
+    // samples).  Piece i < 5: A row m0 + 64 i + row64; piece 5 + j: X row c0 + row64 read at tap shift
+    // (j - 1) * dil.  Which operand / tap a piece belongs to is a compile-time property of i.
+    const int row64 = tid >> 2, pq = tid & 3;
+    const int offa = ((m0 + row64) * (int)a.a_rstride + 4 * pq) * 4;   // byte offsets inside a segment (>= 0)
+    const int offx = ((c0 + row64) * (int)a.x_rstride + 4 * pq) * 4;
+    const int a_step = 64 * (int)a.a_rstride * 4;                      // piece i of A: + i * a_step (scalar)
+    // LDS byte address inside a plane: 16-byte slot of the 8-sample half (pq >> 1), 8-byte half (pq & 1)
+    const int ldsa = ((pq >> 1) * GW_AQ + row64) * 16 + (pq & 1) * 8;                 // piece i: + i * 64 * 16
+    const int ldsx = (GW_ASLOTS + (pq >> 1) * GW_XQ + row64) * 16 + (pq & 1) * 8;     // tap j: + j * 2 * GW_XQ * 16
 
     f32x16 acc[MW][3];
 #pragma unroll
@@ -144,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[4][2], rb[4][2], rc[4][2];                // three staging register sets (chunks k+1 .. k+3)
+    u32x4 ra[8], rb[8], rc[8];                         // three staging register sets (chunks k+1 .. k+3)
 
 #ifdef GW_PROFILE
     long long pt[4] = {0, 0, 0, 0};
@@ -157,9 +144,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     int ld_q = 0;
     int ld_s = (int)(q_begin / cps);
     int ld_c = (int)(q_begin - (long)ld_s * cps);
-    int offb[4];                                       // byte offset of the item inside a segment, without the tap
-#pragma unroll                                         // shift (>= 0: a negative voffset would be out of range)
-    for (int i = 0; i < 4; ++i) offb[i] = off[i] * 4;
     // segment descriptors, rebuilt only when the cursor enters a new segment
     i32x4 qa = gw_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);
     i32x4 qx = gw_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);
@@ -170,23 +154,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
 #define GW_LOAD(R_)                                                                               \
     {                                                                                             \
         const int t0 = ld_c * GW_K;                                                               \
-        const i32x4 q2 = i2_is_a ? qa : qx;                                                       \
         if (!(t0 - halo < 0 || t0 + GW_K + halo > a.T)) {                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-                const i32x4 rs = i < 2 ? qa : i == 2 ? q2 : qx;                                   \
-                const int so = __builtin_amdgcn_readfirstlane((t0 + sh[i]) * 4);   /* >= 0 in interior chunks */ \
-                R_[i][0] = gw_ld128(rs, offb[i], so);                                             \
-                R_[i][1] = gw_ld128_16(rs, offb[i], so);                                          \
-            }                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 5; ++i)                                         \
+                R_[i] = gw_ld128(qa, offa, __builtin_amdgcn_readfirstlane(t0 * 4 + i * a_step));  \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j)         /* t0 + shift >= 0 in interior chunks */ \
+                R_[5 + j] = gw_ld128(qx, offx, __builtin_amdgcn_readfirstlane((t0 + (j - 1) * a.dil) * 4)); \
         } else {                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-                const i32x4 rs = i < 2 ? qa : i == 2 ? q2 : qx;                                   \
-                const int o = off[i] + t0 + sh[i];                                                \
-                const int tt0 = t0 + 8 * (tid & 1) + sh[i];                                       \
-                _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                   \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                       \
+                const i32x4 rs = i < 5 ? qa : qx;                                                 \
+                const int shift = i < 5 ? 0 : (i - 6) * a.dil;                                    \
+                const int tt0 = t0 + 4 * pq + shift;                                              \
+                const int o = (i < 5 ? offa + i * a_step : offx) + (t0 + shift) * 4;              \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
                     const int tt = tt0 + r;                                                       \
-                    const int oo = (tt >= 0 && tt < a.T) ? (o + r) * 4 : 0x7ffffff0;              \
-                    R_[i][r >> 2][r & 3] = gw_ld32(rs, oo);                                       \
+                    const int oo = (tt >= 0 && tt < a.T) ? o + r * 4 : 0x7ffffff0;                \
+                    R_[i][r] = gw_ld32(rs, oo);                                                   \
                 }                                                                                 \
             }                                                                                     \
         }                                                                                         \
@@ -202,15 +184,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     // edge chunk 32 instead of 8 younger loads are outstanding: vmcnt(8) then over-waits, which is safe.)
 #define GW_WAIT(R_, N_)                                                                           \
     asm volatile("s_waitcnt vmcnt(" #N_ ")"                                                       \
-                 : "+v"(R_[0][0]), "+v"(R_[0][1]), "+v"(R_[1][0]), "+v"(R_[1][1]), "+v"(R_[2][0]), \
-                   "+v"(R_[2][1]), "+v"(R_[3][0]), "+v"(R_[3][1])::"memory");
-    // splits item I_ of register set R_ into buffer BUF_
+                 : "+v"(R_[0]), "+v"(R_[1]), "+v"(R_[2]), "+v"(R_[3]), "+v"(R_[4]), "+v"(R_[5]),  \
+                   "+v"(R_[6]), "+v"(R_[7])::"memory");
+    // splits piece I_ of register set R_ into buffer BUF_ (three 8-byte LDS writes, immediate offsets)
 #define GW_STORE(R_, I_, BUF_)                                                                    \
     {                                                                                             \
-        const int slot = (I_) == 0 ? slot0 : (I_) == 1 ? slot1 : (I_) == 2 ? slot2 : slot3;       \
-        float f_[8];                                                                              \
-        _Pragma("unroll") for (int r = 0; r < 8; ++r) f_[r] = __uint_as_float(R_[I_][r >> 2][r & 3]); \
-        gw_split_store(f_, lds + (BUF_) * GW_BUF + slot, GW_ASLOTS + GW_XSLOTS);                  \
+        char* dst_ = reinterpret_cast<char*>(lds + (BUF_) * GW_BUF) +                             \
+                     ((I_) < 5 ? ldsa + (I_) * 64 * 16 : ldsx + ((I_) - 5) * 2 * GW_XQ * 16);     \
+        float f_[4];                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) f_[r] = __uint_as_float(R_[I_][r]);         \
+        gw_split_store4(f_, dst_, (GW_ASLOTS + GW_XSLOTS) * 16);                                  \
     }
 #define GW_TERM(PA_, PB_)                                                                         \
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
@@ -230,29 +213,31 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
         _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[2][j] = __builtin_bit_cast(bf16x8, xb[2 * PS + j * 2 * GW_XQ]); \
     }
     // One stage k.  On entry B.hi, A.lo, B.lo of buffer BUF_ are already in registers (read right after the
-    // barrier of stage k - 1, under its last 30 MFMAs).  Chunk k + 1 (register set ST_) is split into buffer
-    // NBUF_ between the first 60 MFMAs (lo*hi, hi*lo, mid*hi, hi*hi); chunk k + 3 is fetched into register set
-    // LD_ (which held chunk k); then the barrier, the early fragments of stage k + 1, and the last 30 MFMAs
-    // (mid*mid, hi*mid).  Every stage does all of it, the last ones on clamped (repeated) chunks whose
+    // barrier of stage k - 1, under its last 30 MFMAs).  Pieces 0-5 of chunk k + 1 (register set ST_) are split
+    // into buffer NBUF_ between the first 60 MFMAs (lo*hi, hi*lo, mid*hi, hi*hi); then the barrier, the early
+    // fragments of stage k + 1, pieces 6-7 of chunk k + 2 (set S2_) into buffer N2BUF_, the fetch of chunk k + 3
+    // into register set LD_ (which held chunk k), and the last 30 MFMAs (mid*mid, hi*mid).  Every stage does all of it, the last ones on clamped (repeated) chunks whose
     // results are never read.  The order of the six partial products inside a stage is immaterial for the
     // rounding: each is added to the running fp32 sum over all earlier stages.
-#define GW_STAGE(BUF_, NBUF_, LD_, ST_)                                                           \
+#define GW_STAGE(BUF_, NBUF_, N2BUF_, LD_, ST_, S2_)                                              \
     {                                                                                             \
         const u32x4* pb = lds + (BUF_) * GW_BUF;                                                  \
         const u32x4* ab = pb + h * GW_AQ + wm * (MW * 32) + nl;                                   \
         const u32x4* xb = pb + GW_ASLOTS + h * GW_XQ + wc * 32 + nl;                              \
         constexpr int PS = GW_ASLOTS + GW_XSLOTS;                                                 \
         _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(bf16x8, ab[0 * PS + mt * 32]); \
-        GW_WAIT(ST_, 8)               /* chunk k + 1 landed; the 8 loads of chunk k + 2 may stay in flight */ \
+        GW_WAIT(ST_, 8)               /* chunk k + 1 (landed a stage ago); chunk k + 2 may stay in flight */ \
         GW_STORE(ST_, 0, NBUF_)                                                                   \
+        GW_STORE(ST_, 1, NBUF_)                                                                   \
         GW_TERM(2, 0)                                                                             \
         _Pragma("unroll") for (int j = 0; j < 3; ++j) bf[1][j] = __builtin_bit_cast(bf16x8, xb[1 * PS + j * 2 * GW_XQ]); \
         _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(bf16x8, ab[1 * PS + mt * 32]); \
-        GW_STORE(ST_, 1, NBUF_)                                                                   \
-        GW_TERM(0, 2)                                                                             \
         GW_STORE(ST_, 2, NBUF_)                                                                   \
-        GW_TERM(1, 0)                                                                             \
         GW_STORE(ST_, 3, NBUF_)                                                                   \
+        GW_TERM(0, 2)                                                                             \
+        GW_STORE(ST_, 4, NBUF_)                                                                   \
+        GW_STORE(ST_, 5, NBUF_)                                                                   \
+        GW_TERM(1, 0)                                                                             \
         GW_TERM(0, 0)                                                                             \
         /* spread the split arithmetic between the MFMAs: one MFMA, then up to three VALU ops (a VALU */ \
         /* op holds the issue port for 8 cycles, an MFMA for 8 of its 32: scripts/micro/mfma_valu_mix.hip) */ \
@@ -264,9 +249,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
         __syncthreads();                                                                          \
         GW_PSTAMP(1)                                                                              \
         GW_FRAGS_EARLY(NBUF_)                                                                     \
+        GW_WAIT(S2_, 0)               /* chunk k + 2, requested one stage ago */                  \
+        GW_STORE(S2_, 6, N2BUF_)      /* its last two pieces go under the last 30 MFMAs */        \
+        GW_STORE(S2_, 7, N2BUF_)                                                                  \
         GW_LOAD(LD_)                                                                              \
         GW_TERM(1, 1)                                                                             \
         GW_TERM(0, 1)                                                                             \
+        _Pragma("unroll") for (int g_ = 0; g_ < 30; ++g_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                    \
+        }                                                                                         \
         GW_PSTAMP(2)                                                                              \
     }
 
@@ -278,13 +270,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
         GW_WAIT(rb, 0)
         GW_WAIT(rc, 0)
         GW_STORE(ra, 0, 0) GW_STORE(ra, 1, 0) GW_STORE(ra, 2, 0) GW_STORE(ra, 3, 0)
+        GW_STORE(ra, 4, 0) GW_STORE(ra, 5, 0) GW_STORE(ra, 6, 0) GW_STORE(ra, 7, 0)
+        GW_STORE(rb, 6, 1) GW_STORE(rb, 7, 1)
         __syncthreads();
         GW_FRAGS_EARLY(0)
-        // stage k reads buffer k % 3; register set k % 3 held chunk k and now receives chunk k + 3
+        // stage k reads buffer k % 3; register set k % 3 held chunk k and now receives chunk k + 3.  Pieces 0-5
+        // of chunk k + 1 are split before the barrier of stage k, its pieces 6-7 were split after the barrier
+        // of stage k - 1 (into a buffer nobody reads before barrier k).
         for (int k = 0; k < nst; k += 3) {
-            GW_STAGE(0, 1, ra, rb)
-            if (k + 1 < nst) GW_STAGE(1, 2, rb, rc)
-            if (k + 2 < nst) GW_STAGE(2, 0, rc, ra)
+            GW_STAGE(0, 1, 2, ra, rb, rc)
+            if (k + 1 < nst) GW_STAGE(1, 2, 0, rb, rc, ra)
+            if (k + 2 < nst) GW_STAGE(2, 0, 1, rc, ra, rb)
         }
         // The compiler does not know about the asm-issued fetches: the (unused) ones of the last stages are
         // still in flight and would land in registers it hands to the epilogue.  Drain them here.
