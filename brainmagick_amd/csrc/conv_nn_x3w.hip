@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
     LOAD_X(0)
     CW_WAIT_X(0)
     STORE_X(0)
+    if (KS == 1) LOAD_X(1)          // 1x1 convs: the window of chunk c + 2 is requested in stage c (see below)
     CW_BARRIER(0)
     FRAGS_EARLY(0, 0, 0)
 
@@ -185,6 +186,18 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
     // stage: [input window of chunk c16 + 1, 16 loads, if j == 0], slab s + 2 (8 DMA copies).  Before the
     // barrier slab s + 1 must have landed: younger than it are 8 (+ 16 if j == 0) instructions.  The input
     // window is consumed in the stage with j == KS - 1: younger than it are the KS slabs issued since.
+    // KS == 1 (every stage is a window stage): the window of chunk c + 1 was requested in stage c - 1 after its
+    // slab; it is split in stage c, and only then is the window of chunk c + 2 requested into the same
+    // registers - queue order per stage: slab s + 2 (8), window s + 2 (16); younger than slab s + 1 at the
+    // barrier: window s + 1, slab s + 2, window s + 2 = 40.
+#ifdef WIDE_PROFILE
+    long long pt[3] = {0, 0, 0};
+    long long plast = clock64();
+    const long long pstart = plast;
+#define CW_PSTAMP(I_) { const long long now_ = clock64(); pt[I_] += now_ - plast; plast = now_; }
+#else
+#define CW_PSTAMP(I_)
+#endif
     int s = 0;
     int ab3 = 0;                                      // s % 3
     for (int c16 = 0; c16 < n16; ++c16) {
@@ -193,12 +206,13 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
         for (int j = 0; j < KS; ++j, ++s) {
             const int ab_next = ab3 == 2 ? 0 : ab3 + 1;
             const int ab_next2 = ab_next == 2 ? 0 : ab_next + 1;
-            if (j == 0) LOAD_X(c16 + 1)
+            if (KS != 1 && j == 0) LOAD_X(c16 + 1)
             DMA_A(s + 2, ab_next2)
             FRAGS_LATE(ab3, xbuf, j)
             if (j == KS - 1) {
                 if (KS == 3) CW_WAIT_X(24) else CW_WAIT_X(8)
                 STORE_X(xbuf ^ 1)
+                if (KS == 1) LOAD_X(c16 + 2)
             }
             TERM(2, 0) TERM(0, 2) TERM(1, 0) TERM(0, 0)
             if (j == KS - 1) {       // spread the split arithmetic of the input window between the MFMAs
@@ -207,12 +221,22 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 }
             }
-            if (j == 0) CW_BARRIER(24) else CW_BARRIER(8)
+            CW_PSTAMP(0)
+            if (KS == 1) CW_BARRIER(40) else if (j == 0) CW_BARRIER(24) else CW_BARRIER(8)
+            CW_PSTAMP(1)
             if (j == KS - 1) FRAGS_EARLY(ab_next, xbuf ^ 1, 0) else FRAGS_EARLY(ab_next, xbuf, j + 1)
             TERM(1, 1) TERM(0, 1)
+            CW_PSTAMP(2)
             ab3 = ab_next;
         }
     }
+#ifdef WIDE_PROFILE
+    if (a.stats && blockIdx.x == 0 && lane == 0) {   // profiling builds only: the stats buffer carries the stamps
+        float* d = a.stats + wave * 8;
+        for (int i = 0; i < 3; ++i) d[i] = (float)(pt[i] / nstage);
+        d[3] = (float)((clock64() - pstart) / nstage);
+    }
+#endif
     // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #undef DMA_A
@@ -269,7 +293,9 @@ static int x3w_enabled() {
 }
 
 static bool x3w_covers(int Cin, int Mpad, int T, int KS, int dil, bool with_stats) {
+#ifndef WIDE_PROFILE
     if (with_stats) return false;
+#endif
     if (!x3w_enabled() || Mpad % WBM != 0 || (KS != 1 && KS != 3)) return false;
     if ((KS >> 1) * dil > 16 || T <= 128) return false;
     return (long)Cin * T * 4 < 0x40000000L;
