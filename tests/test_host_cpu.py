@@ -200,3 +200,13 @@ def test_wide_kernels_do_not_spill(tmp_path):
                         f"-I{csrc}", "-o", str(out), str(csrc / name)], check=True, capture_output=True)
         spills = [int(l.split(":")[1]) for l in out.read_text().splitlines() if ".vgpr_spill_count" in l]
         assert spills and all(s == 0 for s in spills), (name, spills)
+
+
+def test_deep_mel_known_answer_of_the_reference():
+    """The one test the reference holds for this path (bm/test_model.py:53-68): DeepMel built from the same
+    arguments has `n_hidden_layers` blocks; the output shape half of it runs on the GPU
+    (tests/test_model_gpu.py::test_deep_mel_shape_like_reference)."""
+    from brainmagick_amd.models import DeepMel
+    model = DeepMel(8, 3, 5, 2, kernel=3, stride=1, dilation_growth=2, dilation_period=5, batch_norm=True,
+                    activation_on_last=False, skip=True, glu_context=1, glu=2)
+    assert len(model.sequence) == 5

@@ -502,3 +502,15 @@ def test_rejected_batch_reuses_last_and_nonfinite_asserts():
     nan.features[0, 0, 0] = float("nan")
     with pytest.raises(AssertionError):
         Solver(_small_model()[0]).train_step(nan)
+
+
+def test_deep_mel_shape_like_reference():
+    """bm/test_model.py:53-68 (fake_batch features [2, 8, 128]): output keeps batch and time, n_out channels."""
+    from brainmagick_amd.models import DeepMel
+    torch.manual_seed(0)
+    features = torch.randn(2, 8, 128).cuda()
+    model = DeepMel(8, 3, 5, 2, kernel=3, stride=1, dilation_growth=2, dilation_period=5, batch_norm=True,
+                    activation_on_last=False, skip=True, glu_context=1, glu=2).cuda()
+    out = model(features)
+    assert len(model.sequence) == 5
+    assert out.shape == (features.shape[0], 2, features.shape[2])
