@@ -56,6 +56,9 @@ __device__ __forceinline__ float cw_ld32(i32x4w rs, int voff) {
 
 template <int KS>
 __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
+#ifdef WIDE_PROFILE
+    const long long pentry = clock64();
+#endif
     constexpr int MW = 5, NW = 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* As = reinterpret_cast<u32x4*>(smem);       // [3 buffers][3 planes][2 groups][WBM]
@@ -235,7 +238,10 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
         float* d = a.stats + wave * 8;
         for (int i = 0; i < 3; ++i) d[i] = (float)(pt[i] / nstage);
         d[3] = (float)((clock64() - pstart) / nstage);
+        d[4] = (float)(pstart - pentry);              // prologue
+        d[5] = (float)(clock64() - pstart);           // main loop
     }
+    const long long pmain_end = clock64();
 #endif
     // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -253,6 +259,41 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
     float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
     conv_ep_stage_params(a, ep, WBM, m0, tid, 256);
     __syncthreads();
+    // Common case (every wide launch of the training step): one output tensor, no affine / activation, tile
+    // fully inside M.  Row addresses are wave-uniform bases + one per-lane offset + an immediate per column
+    // block, the 80 row biases are read once: ~3 VALU issue slots per stored element instead of ~10.
+    const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE &&
+                        m0 + WBM <= a.M;
+    if (simple) {
+        float* yb = (a.y_pre ? a.y_pre : a.y_out) + (long)b * a.y_bstride;
+        const float* rb = (a.y_out && a.res) ? a.res + (long)b * a.res_bstride : nullptr;
+        const int rowu = m0 + wm * (MW * 32);                       // wave-uniform first row
+        const int li = 4 * h * a.T + n0 + wn * (NW * 32) + nl;      // per-lane element offset inside a row block
+        const float* epl = ep + wm * (MW * 32) + 4 * h;
+        float bia[MW][16];
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bia[mt][r] = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+#define EPS(MT_, NT_)                                                                             \
+    {                                                                                             \
+        float rv_[16];                                                                            \
+        if (rb) {                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                        \
+                rv_[r] = rb[(long)(rowu + (MT_) * 32 + (r & 3) + 8 * (r >> 2)) * a.T + li + (NT_) * 32]; \
+        }                                                                                         \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+            float v_ = acc[MT_][NT_][r] + bia[MT_][r];                                            \
+            if (rb) v_ += rv_[r];                                                                 \
+            yb[(long)(rowu + (MT_) * 32 + (r & 3) + 8 * (r >> 2)) * a.T + li + (NT_) * 32] = v_;  \
+        }                                                                                         \
+    }
+#define EPS_COL(NT_)                                                                              \
+    if (n0 + wn * (NW * 32) + (NT_) * 32 + nl < a.T) { EPS(0, NT_) EPS(1, NT_) EPS(2, NT_) EPS(3, NT_) EPS(4, NT_) }
+        EPS_COL(0) EPS_COL(1) EPS_COL(2)
+#undef EPS_COL
+#undef EPS
+    } else {
 #define EPI(MT_, NT_)                                                                             \
     {                                                                                             \
         float v_[16];                                                                             \
@@ -260,9 +301,20 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
                             n0 + wn * (NW * 32) + (NT_) * 32 + nl, v_);                           \
     }
 #define EPI_ROW(MT_) EPI(MT_, 0) EPI(MT_, 1) EPI(MT_, 2)
-    EPI_ROW(0) EPI_ROW(1) EPI_ROW(2) EPI_ROW(3) EPI_ROW(4)
+        EPI_ROW(0) EPI_ROW(1) EPI_ROW(2) EPI_ROW(3) EPI_ROW(4)
 #undef EPI_ROW
 #undef EPI
+    }
+#ifdef WIDE_PROFILE
+    {
+        const long long issued = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.stats && blockIdx.x == 0 && lane == 0) {
+            a.stats[wave * 8 + 6] = (float)(issued - pmain_end);        // epilogue instructions issued
+            a.stats[wave * 8 + 7] = (float)(clock64() - pmain_end);     // ... and stores drained
+        }
+    }
+#endif
 }
 
 template <int KS>

@@ -17,4 +17,5 @@ for (Cin, M, KS, dil) in [(320, 320, 3, 1), (320, 320, 3, 16), (320, 640, 1, 1)]
     v = st.flatten()[:32].cpu().view(4, 8)
     print(f"{Cin}->{M} k{KS} d{dil}: per stage cycles [first 60 MFMAs (+ window split) | barrier | last 30 MFMAs + next fragments | total]")
     for w_ in range(4):
-        print("   wave", w_, [int(t) for t in v[w_, :4]])
+        print("   wave", w_, [int(t) for t in v[w_, :4]], "| prologue", int(v[w_, 4]), "main", int(v[w_, 5]),
+              "epilogue issued", int(v[w_, 6]), "drained", int(v[w_, 7]))
