@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     u32x4 ra[8], rb[8], rc[8];                         // three staging register sets (chunks k+1 .. k+3)
 
 #ifdef GW_PROFILE
-    long long pt[4] = {0, 0, 0, 0};
+    long long pt[5] = {0, 0, 0, 0, 0};
     long long plast = clock64();
     const long long pstart = plast;
 #define GW_PSTAMP(I_) { const long long now_ = clock64(); pt[I_] += now_ - plast; plast = now_; }
@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
         __syncthreads();                                                                          \
         GW_PSTAMP(1)                                                                              \
         GW_FRAGS_EARLY(NBUF_)                                                                     \
+        GW_PSTAMP(2)                                                                              \
         GW_WAIT(S2_, 0)               /* chunk k + 2, requested one stage ago */                  \
+        GW_PSTAMP(3)                                                                              \
         GW_STORE(S2_, 6, N2BUF_)      /* its last two pieces go under the last 30 MFMAs */        \
         GW_STORE(S2_, 7, N2BUF_)                                                                  \
         GW_LOAD(LD_)                                                                              \
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                    \
         }                                                                                         \
-        GW_PSTAMP(2)                                                                              \
+        GW_PSTAMP(4)                                                                              \
     }
 
     if (nst > 0) {
@@ -319,9 +321,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x3w_kernel(GemmNTArgsW a) {
     __syncthreads();
     if (blockIdx.x == 0 && lane == 0) {     // overwrites the head of the partial buffer: profiling builds only
         float* d = a.part + wave * 8;
-        for (int i = 0; i < 4; ++i) d[i] = (float)(pt[i] / nst);
-        d[4] = (float)(ptotal / nst);
-        d[5] = (float)nst;
+        for (int i = 0; i < 5; ++i) d[i] = (float)(pt[i] / nst);
+        d[5] = (float)(ptotal / nst);
+        d[6] = (float)nst;
     }
 #endif
 }

@@ -17,6 +17,6 @@ for dil in (1, 16):
                                   B, 1, M, Cin, T, KS, dil, ns, None), "gemm")
     torch.cuda.synchronize()
     v = part[:32].cpu().view(4, 8)
-    print(f"dil {dil} nsplit {ns}: per stage [first 60 MFMAs + split | barrier | last 30 MFMAs + fetch | - | total] stages")
+    print(f"dil {dil} nsplit {ns}: per stage [first 60 MFMAs + split | barrier | early fragments | vm wait | pieces 6-7 + fetch + last 30 MFMAs | total] stages")
     for w in range(4):
-        print("   wave", w, [int(t) for t in v[w, :6]])
+        print("   wave", w, [int(t) for t in v[w, :7]])
