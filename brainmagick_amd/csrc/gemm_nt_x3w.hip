@@ -1,5 +1,6 @@
 // Wide-tile variant of the fp32-accurate ("f32x3") time-contraction GEMM of gemm_nt_x3.hip for the
-// weight gradients of the conv stack (M a multiple of 320, Cn a multiple of 64, 3 taps, one group):
+// weight gradients of the conv stack (3 taps, one group; M / Cn padded to multiples of 320 / 64 by the bounds
+// check when that wastes at most a quarter of the work):
 //
 //   part[split][m][c*3 + j] = sum_{s, t in split} A[s][m][t] * X[s][c][t + (j - 1) * dil]
 //
@@ -335,7 +336,11 @@ static bool gw_covers(int S, int G, int M, int Cn, int T, int KS, int dil, bool 
         wide = !(e && e[0] == '0');
     }
     if (!wide || G != 1 || ordered || KS != 3) return false;
-    if (M % GW_BM != 0 || Cn % GW_BC != 0 || dil < 1 || dil > 32 || T < 2 * GW_K) return false;
+    if (dil < 1 || dil > 32 || T < 2 * GW_K) return false;
+    // rows past M / Cn read as zeros (their byte offset alone is past the descriptor's range) and are never
+    // written; take the wide kernel while the padded tile grid wastes at most a quarter of the work
+    const long padded = (long)cdiv(M, GW_BM) * GW_BM * cdiv(Cn, GW_BC) * GW_BC;
+    if (padded * 4 > (long)M * Cn * 5) return false;
     return (long)S * ((T + GW_K - 1) / GW_K) >= 64;
 }
 
@@ -344,7 +349,7 @@ static bool gw_covers(int S, int G, int M, int Cn, int T, int KS, int dil, bool 
 extern "C" int bm_gemm_nt_suggest_splits(int M, int Cn, int KS, int S, int T, int G);
 extern "C" int bm_gemm_nt_x3_suggest_splits(int M, int Cn, int KS, int S, int T, int G, int dil) {
     if (!gw_covers(S, G, M, Cn, T, KS, dil, false)) return bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G);
-    const int tiles = (M / GW_BM) * (Cn / GW_BC);
+    const int tiles = cdiv(M, GW_BM) * cdiv(Cn, GW_BC);
     long chunks = (long)S * ((T + GW_K - 1) / GW_K);
     long want = 256 / tiles;
     if (want < 1) want = 1;
@@ -363,7 +368,7 @@ int bm_gemm_nt_x3w_try(const float* a, long a_sstride, long a_rstride, const flo
     g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride;
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride;
     g.part = part; g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit;
-    g.tiles_m = M / GW_BM; g.tiles_c = Cn / GW_BC;
+    g.tiles_m = cdiv(M, GW_BM); g.tiles_c = cdiv(Cn, GW_BC);
     const size_t lds = (size_t)3 * GW_BUF * 16;
     static bool attr_set = false;
     if (!attr_set) {
