@@ -111,11 +111,58 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
     }
 }
 
+// Same sum, four consecutive partial-tile elements per thread (one dwordx4 per split, eight splits in
+// flight), for per % 4 == 0.  The order of the additions per element is the same k = 0, 1, ... as above.
+__global__ void reduce_splits_vec4_kernel(const float* __restrict__ part, float* __restrict__ out, int G,
+                                          int nsplit, int M, int Cn, int KS, long sg, long sm, long sc,
+                                          long sj) {
+    const long N = (long)Cn * KS;
+    const long per = (long)M * N;
+    const long total4 = (long)G * per / 4;
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4;
+         i4 += (long)gridDim.x * blockDim.x) {
+        const long i = i4 * 4;
+        const int g = (int)(i / per);
+        const long r = i - (long)g * per;
+        const float* p = part + (long)g * nsplit * per + r;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(k + u) * per);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (long)k * per);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long re = r + e;
+            const int m = (int)(re / N);
+            const int n = (int)(re - (long)m * N);
+            const int c = n / KS, j = n - c * KS;
+            out[g * sg + m * sm + c * sc + j * sj] = sv[e];
+        }
+    }
+}
+
 extern "C" int bm_reduce_splits(const float* part, float* out, int G, int nsplit, int M, int Cn,
                                 int KS, long sg, long sm, long sc, long sj, void* stream) {
     BM_REQUIRE(part && out, "reduce_splits: null pointer");
     const long total = (long)G * M * Cn * KS;
     if (total <= 0) return BM_OK;
+    const long per = (long)M * Cn * KS;
+    if (per % 4 == 0 && ((uintptr_t)part % 16) == 0) {
+        const long t4 = total / 4;
+        const int blocks = (int)((t4 + 255) / 256 > 8192 ? 8192 : (t4 + 255) / 256);
+        hipLaunchKernelGGL(reduce_splits_vec4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part,
+                           out, G, nsplit, M, Cn, KS, sg, sm, sc, sj);
+        return bm_check_launch("reduce_splits");
+    }
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part,
                        out, G, nsplit, M, Cn, KS, sg, sm, sc, sj);
