@@ -42,6 +42,8 @@ CONV_CASES = [
     (320, 320, 3, 2, 360, 4),
     (64, 640, 3, 16, 343, 3),
     (128, 320, 3, 1, 361, 3),
+    (40, 320, 3, 7, 577, 1),       # Cin not a multiple of 16, odd dilation, last 192-column tile holds 1 column
+    (16, 320, 1, 1, 129, 1),       # a single, mostly empty time tile
 ]
 
 
