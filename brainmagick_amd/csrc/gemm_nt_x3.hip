@@ -290,6 +290,10 @@ int bm_gemm_nt_x3w_try(const float* a, long a_sstride, long a_rstride, const flo
                        long x_rstride, const int* order, float* part, int S, int G, int M, int Cn, int T,
                        int KS, int dil, int nsplit, hipStream_t stream);   // gemm_nt_x3w.hip
 
+extern "C" int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
+                          long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
+                          int Cn, int T, int KS, int dil, int nsplit, void* stream);   // gemm_nt.hip
+
 static inline bool prefer_big_x(int n) { return (long)cdiv(n, 128) * 128 <= (long)cdiv(n, 64) * 64; }
 
 // Same contract as bm_gemm_nt (fp32 partial tiles out); fp32-accurate 3-plane bf16 emulation.
@@ -300,6 +304,12 @@ extern "C" int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, con
     BM_REQUIRE(a && x && part, "gemm_nt_x3: null pointer");
     BM_REQUIRE(M > 0 && Cn > 0 && T > 0 && G > 0 && nsplit > 0 && S >= 0, "gemm_nt_x3: bad dims");
     BM_REQUIRE(G == 1 || seg, "gemm_nt_x3: grouped call needs seg[]");
+    // The staging addresses are 32-bit byte offsets into one segment (buffer descriptors).  An operand whose
+    // segment spans 2 GB or more (e.g. 2 048 wav2vec candidates x 368 640 samples on 8 GPUs) goes through the
+    // exact-fp32 kernel, which addresses with 64-bit pointers (same contract, at least as accurate).
+    if (((long)(M - 1) * a_rstride + T) * 4 >= 0x7fffff00L || ((long)(Cn - 1) * x_rstride + T) * 4 >= 0x7fffff00L)
+        return bm_gemm_nt(a, a_sstride, a_rstride, x, x_sstride, x_rstride, order, seg, part, S, G, M, Cn, T, KS,
+                          dil, nsplit, stream);
     GemmNTArgsX g;
     g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride;
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride;

@@ -448,3 +448,19 @@ def test_wide_and_narrow_f32x3_kernels_agree(tmp_path):
     assert outs["wide"]["wide"] == 1 and outs["narrow"]["wide"] == 0
     for k in ("y", "dx", "dw"):
         assert rel_l2(outs["wide"][k], outs["narrow"][k].double()) < 2e-6, k
+
+
+def test_scores_contraction_with_an_operand_over_2gb(H):
+    """Whole-node negatives with wav2vec-sized features: 2 048 candidates x (F*T) samples exceed the 2 GB a
+    32-bit buffer offset can address; the f32x3 entry point must route that call to the 64-bit-addressing
+    kernel instead of wrapping around."""
+    M, Cn, K = 32, 2048, 270_016
+    g = torch.Generator(device="cuda").manual_seed(7)
+    est = torch.randn(M, K, device="cuda", generator=g)
+    cand = torch.randn(Cn, K, device="cuda", generator=g)
+    assert cand.numel() * 4 > 2 ** 31
+    out = H.gemm_nt(est, cand, 1, M, Cn, K, a_strides=(0, K), x_strides=(0, K))[0, :, :, 0]
+    ref = est.double() @ cand.double().t()
+    assert rel_l2(out, ref) < 2e-6
+    del est, cand, ref
+    torch.cuda.empty_cache()
