@@ -1,6 +1,6 @@
 // Wide-tile variant of the fp32-accurate ("f32x3") time-contraction GEMM of gemm_nt_x3.hip for the
-// weight gradients of the conv stack (3 taps, one group; M / Cn padded to multiples of 320 / 64 by the bounds
-// check when that wastes at most a quarter of the work):
+// weight gradients of the conv stack (3 taps, one group; M a multiple of 320, Cn padded to a multiple of 64
+// by the bounds check when that wastes at most a quarter of the work):
 //
 //   part[split][m][c*3 + j] = sum_{s, t in split} A[s][m][t] * X[s][c][t + (j - 1) * dil]
 //
@@ -339,6 +339,10 @@ static bool gw_covers(int S, int G, int M, int Cn, int T, int KS, int dil, bool 
     if (dil < 1 || dil > 32 || T < 2 * GW_K) return false;
     // rows past M / Cn read as zeros (their byte offset alone is past the descriptor's range) and are never
     // written; take the wide kernel while the padded tile grid wastes at most a quarter of the work
+    // (the X rows are addressed through the per-lane voffset, which the descriptor range-checks; the A rows
+    // of pieces 1..4 are addressed through the scalar soffset, which is NOT range-checked, so A is never
+    // padded: M must fill its 320-row tiles)
+    if (M % GW_BM != 0) return false;
     const long padded = (long)cdiv(M, GW_BM) * GW_BM * cdiv(Cn, GW_BC) * GW_BC;
     if (padded * 4 > (long)M * Cn * 5) return false;
     return (long)S * ((T + GW_K - 1) / GW_K) >= 64;

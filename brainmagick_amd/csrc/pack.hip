@@ -89,6 +89,30 @@ extern "C" int bm_group_by_index(const long* idx, int B, int G, int* order, int*
     return bm_check_launch("group_by_index");
 }
 
+// int64 group indices (subject_index, layout index) -> int32 for the grouped conv kernels, range-checked:
+// an index outside [0, G) sets *err (the reference's W[subjects] gather, bm/models/common.py:57, raises on
+// it) and is replaced by 0 so that no kernel ever reads outside the weight table.
+__global__ void index_to_i32_kernel(const long* __restrict__ idx, int B, int G, int* __restrict__ out,
+                                    int* __restrict__ err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    long v = idx[i];
+    if (v < 0 || v >= G) {
+        if (err) atomicExch(err, 1);
+        v = 0;
+    }
+    out[i] = (int)v;
+}
+
+extern "C" int bm_index_to_i32(const long* idx, int B, int G, int* out, int* err_flag, void* stream) {
+    BM_REQUIRE(idx && out, "index_to_i32: null pointer");
+    BM_REQUIRE(B >= 0 && G > 0, "index_to_i32: bad dims B=%d G=%d", B, G);
+    if (B == 0) return BM_OK;
+    hipLaunchKernelGGL(index_to_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, B,
+                       G, out, err_flag);
+    return bm_check_launch("index_to_i32");
+}
+
 // out[g*sg + m*sm + c*sc + j*sj] = sum_split part[(g*nsplit + split)][m][c*KS + j]
 // (fixed summation order -> deterministic split-K).
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int G,

@@ -1,21 +1,30 @@
 """Data-parallel exchange of the hot path: the replacement for the ``flashy.distrib`` calls on the
-training step: one process per GPU, ``torch.distributed`` ("nccl" backend = RCCL
-over xGMI on ROCm; "gloo" for the CPU tests).
+training step, one process per GPU.
 
-* C3 ``sync_model`` (bm/solver.py:386): ``sync_flat_gradients`` -- ONE reduce-scatter on the flat
-  gradient bucket, the rank updates its shard with the fused Adam, then ONE all-gather of the
-  updated parameters.  Same bytes on the wire as an all-reduce, 1/N of the optimizer work, two
-  large collectives instead of 58 small ones (xGMI is point-to-point: few, large messages).
+Data plane on the GPU = RCCL behind the C-ABI (``bm_comm_*`` in include/bm_hip.h, csrc/comm.hip):
+the 128-byte unique id travels through the rendezvous TCP store (MASTER_ADDR / MASTER_PORT of the
+torchrun environment), every collective is enqueued on a HIP stream by libbmhip -- PyTorch only owns
+the buffers.  ``torch.distributed`` is used for the CPU tests ("gloo") and as an explicit fallback
+(``BM_COMM=torch`` or ``init("nccl")``).
+
+* C3 ``sync_model`` (bm/solver.py:386): ``sharded_step`` -- ONE in-place reduce-scatter on the flat
+  gradient bucket, the rank updates its shard with the fused Adam (mean over ranks folded in as
+  ``grad_scale``), then ONE in-place all-gather of the updated parameters.  Same bytes on the wire
+  as an all-reduce, 1/N of the optimizer work, two large collectives instead of 58 small ones
+  (xGMI is point-to-point: few, large messages).  Float buffers (BatchNorm running statistics) are
+  averaged like flashy's ``sync_model`` does, through ONE flat all-reduce (``BufferBucket``).
 * C7 (new vs the reference, which keeps negatives per-GPU -- README.md:139-143): ``CandidateGather``
   all-gathers the precomputed audio candidates of every rank on a side stream, overlapped with the
-  SimpleConv forward (candidates are inputs: no dependence on the model), in rank
-  order; a rank's targets are its own block, selected with ``ClipLoss.forward(..., target_offset=
-  rank*B)`` (the reference contract "first B candidates are the targets", bm/losses.py:105-111, is
-  the offset-0 case) -- no re-ordering copy of the (up to 3 GB) gathered tensor.
+  SimpleConv forward (candidates are inputs: no dependence on the model), in rank order; a rank's
+  targets are its own block, selected with ``ClipLoss.forward(..., target_offset=rank*B)`` (the
+  reference contract "first B candidates are the targets", bm/losses.py:105-111, is the offset-0
+  case) -- no re-ordering copy of the (up to 3 GB) gathered tensor.
 * C4 ``average_metrics`` (bm/solver.py:395): tiny all-reduce.
 
 Everything degrades to a no-op at world_size 1.
 """
+import ctypes
+import datetime
 import os
 import typing as tp
 
@@ -29,35 +38,222 @@ def _forced() -> bool:
     return os.environ.get("BM_FORCE_DISTRIBUTED", "0") == "1"
 
 
+# ------------------------------------------------------------------------------------------------
+# communicators
+# ------------------------------------------------------------------------------------------------
+class _TorchComm:
+    """torch.distributed process group: "gloo" (CPU tests) or "nccl" (= RCCL through PyTorch, fallback)."""
+
+    def __init__(self, backend: str):
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if backend == "gloo" and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container hostname may not resolve
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend)
+        self.backend = backend
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.kind = f"torch.distributed/{backend}"
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        dist.all_gather_into_tensor(out, inp)
+
+    def reduce_scatter_shard(self, flat: torch.Tensor):
+        """In place: afterwards shard `rank` of ``flat`` holds the sum over ranks of that shard."""
+        lo, hi = shard_bounds(flat.numel(), self.world, self.rank)
+        if self.backend == "gloo":
+            dist.all_reduce(flat)          # gloo has no reduce_scatter (CPU tests only)
+            return
+        out = torch.empty(hi - lo, device=flat.device, dtype=flat.dtype)
+        dist.reduce_scatter_tensor(out, flat)
+        flat[lo:hi].copy_(out)
+
+    def all_gather_shards(self, flat: torch.Tensor):
+        lo, hi = shard_bounds(flat.numel(), self.world, self.rank)
+        dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
+
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor):
+        if self.backend == "gloo":
+            tmp = inp.clone()
+            dist.all_reduce(tmp)
+            n = out.numel()
+            out.copy_(tmp.reshape(-1)[self.rank * n:(self.rank + 1) * n].view_as(out))
+            return
+        dist.reduce_scatter_tensor(out, inp)
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum"):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+
+    def barrier(self):
+        dist.barrier()
+
+    def scalar_device(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def close(self):
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _rendezvous_store(rank: int, world: int):
+    """The TCP store of the torchrun / env:// rendezvous (the agent's store under torchrun, else rank 0
+    hosts it on MASTER_ADDR:MASTER_PORT).  Host-side key/value plumbing only."""
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    return dist.TCPStore(host, port, world, is_master=(rank == 0 and not agent),
+                         timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+
+
+class _RcclComm:
+    """RCCL behind the C-ABI (bm_comm_*)."""
+    _generation = 0
+
+    def __init__(self):
+        from ._lib import lib, check
+        self._lib, self._check = lib(), check
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.device)
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if "BM_RCCL_LIB" not in os.environ and os.path.exists(rccl):
+            os.environ["BM_RCCL_LIB"] = rccl           # the copy PyTorch ships and tests on this driver
+        nbytes = self._lib.bm_comm_unique_id_bytes()
+        key = f"bm_comm/{_RcclComm._generation}/id"
+        _RcclComm._generation += 1
+        if self.world == 1:
+            uid = ctypes.create_string_buffer(nbytes)
+            check(self._lib.bm_comm_unique_id(uid), "bm_comm_unique_id")
+            uid = uid.raw
+            self._store = None
+        else:
+            self._store = _rendezvous_store(self.rank, self.world)
+            if self.rank == 0:
+                buf = ctypes.create_string_buffer(nbytes)
+                check(self._lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
+                self._store.set(key, buf.raw)
+            uid = bytes(self._store.get(key))
+        handle = ctypes.c_void_p()
+        check(self._lib.bm_comm_init(uid, self.world, self.rank, self.device, ctypes.byref(handle)),
+              "bm_comm_init")
+        self._h = handle
+        self.kind = "rccl/c-abi"
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"bm_comm.{name}: expected a contiguous fp32 GPU tensor")
+        return t
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        self._f32(out, "allgather"), self._f32(inp, "allgather")
+        assert out.numel() == self.world * inp.numel()
+        self._check(self._lib.bm_comm_allgather(self._h, ctypes.c_void_p(inp.data_ptr()),
+                                                ctypes.c_void_p(out.data_ptr()), inp.numel(), self._stream()),
+                    "bm_comm_allgather")
+
+    def reduce_scatter_shard(self, flat: torch.Tensor):
+        self._f32(flat, "reduce_scatter")
+        lo, hi = shard_bounds(flat.numel(), self.world, self.rank)
+        # in place: recv == send + rank * count
+        self._check(self._lib.bm_comm_reduce_scatter(self._h, ctypes.c_void_p(flat.data_ptr()),
+                                                     ctypes.c_void_p(flat.data_ptr() + 4 * lo), hi - lo,
+                                                     self._stream()), "bm_comm_reduce_scatter")
+
+    def all_gather_shards(self, flat: torch.Tensor):
+        self._f32(flat, "allgather")
+        lo, hi = shard_bounds(flat.numel(), self.world, self.rank)
+        # in place: send == recv + rank * count
+        self._check(self._lib.bm_comm_allgather(self._h, ctypes.c_void_p(flat.data_ptr() + 4 * lo),
+                                                ctypes.c_void_p(flat.data_ptr()), hi - lo, self._stream()),
+                    "bm_comm_allgather")
+
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor):
+        self._f32(out, "reduce_scatter"), self._f32(inp, "reduce_scatter")
+        assert inp.numel() == self.world * out.numel()
+        self._check(self._lib.bm_comm_reduce_scatter(self._h, ctypes.c_void_p(inp.data_ptr()),
+                                                     ctypes.c_void_p(out.data_ptr()), out.numel(),
+                                                     self._stream()), "bm_comm_reduce_scatter")
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum"):
+        self._f32(t, "allreduce")
+        self._check(self._lib.bm_comm_allreduce(self._h, ctypes.c_void_p(t.data_ptr()),
+                                                ctypes.c_void_p(t.data_ptr()), t.numel(),
+                                                0 if op == "sum" else 1, self._stream()), "bm_comm_allreduce")
+
+    def barrier(self):
+        t = torch.zeros(1, device="cuda", dtype=torch.float32)
+        self.all_reduce(t)
+        torch.cuda.current_stream().synchronize()
+
+    def scalar_device(self):
+        return "cuda"
+
+    def close(self):
+        if self._h:
+            torch.cuda.synchronize()
+            self._lib.bm_comm_destroy(self._h)
+            self._h = None
+
+
+_comm: tp.Optional[tp.Any] = None
+
+
+def comm():
+    return _comm
+
+
+def comm_kind() -> str:
+    return _comm.kind if _comm is not None else "none"
+
+
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
+    return _comm is not None and (_comm.world > 1 or _forced())
 
 
 def rank() -> int:
-    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return _comm.rank if _comm is not None else 0
 
 
 def world_size() -> int:
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return _comm.world if _comm is not None else 1
 
 
 def init(backend: tp.Optional[str] = None):
-    """flashy.distrib.init (bm/train.py:139): rendezvous from the torchrun environment."""
+    """flashy.distrib.init (bm/train.py:139): rendezvous from the torchrun environment
+    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).
+
+    backend: "rccl" (default on a GPU: RCCL behind the C-ABI), "gloo" (default on CPU), "nccl"
+    (torch.distributed's RCCL binding; also chosen with BM_COMM=torch)."""
+    global _comm
     if "RANK" not in os.environ or (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not _forced()):
         return
-    if dist.is_initialized():
+    if _comm is not None:
         return
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend=backend)
+    if backend is None:
+        backend = "rccl" if torch.cuda.is_available() else "gloo"
+        if backend == "rccl" and os.environ.get("BM_COMM", "") == "torch":
+            backend = "nccl"
+    _comm = _RcclComm() if backend == "rccl" else _TorchComm(backend)
+
+
+def shutdown():
+    global _comm
+    if _comm is not None:
+        _comm.close()
+        _comm = None
 
 
 def barrier():
     if is_distributed():
-        dist.barrier()
+        _comm.barrier()
 
 
 def shard_bounds(numel: int, world: int, r: int) -> tp.Tuple[int, int]:
@@ -67,53 +263,71 @@ def shard_bounds(numel: int, world: int, r: int) -> tp.Tuple[int, int]:
     return r * per, (r + 1) * per
 
 
-def _reduce_scatter_sum(flat: torch.Tensor, world: int, r: int) -> None:
-    """In place: afterwards shard r of ``flat`` holds the sum over ranks of that shard."""
-    lo, hi = shard_bounds(flat.numel(), world, r)
-    if dist.get_backend() == "gloo":
-        # gloo has no reduce_scatter: all-reduce then keep the own shard (CPU tests only)
-        dist.all_reduce(flat)
-        return
-    out = torch.empty(hi - lo, device=flat.device, dtype=flat.dtype)
-    dist.reduce_scatter_tensor(out, flat)
-    flat[lo:hi].copy_(out)
+def all_gather_shards(flat: torch.Tensor) -> None:
+    """Every rank holds a valid shard `rank` of ``flat``; afterwards all of ``flat`` is valid everywhere."""
+    if is_distributed():
+        _comm.all_gather_shards(flat)
 
 
 def sync_flat_gradients(optimizer, average: bool = True) -> tp.Optional[tp.Tuple[int, int]]:
-    """Reduce-scatter the flat gradient bucket; returns this rank's shard bounds (None when not
-    distributed).  Gradient averaging (flashy sync_model semantics) is folded in the Adam kernel
+    """Reduce-scatter the flat gradient bucket in place; returns this rank's shard bounds (None when
+    not distributed).  Gradient averaging (flashy sync_model semantics) is folded in the Adam kernel
     through ``grad_scale`` by ``sharded_step``."""
     if not is_distributed():
         return None
-    world, r = world_size(), rank()
-    _reduce_scatter_sum(optimizer.flat_grad, world, r)
-    return shard_bounds(optimizer.flat_grad.numel(), world, r)
+    _comm.reduce_scatter_shard(optimizer.flat_grad)
+    return shard_bounds(optimizer.flat_grad.numel(), world_size(), rank())
 
 
-def sharded_step(optimizer) -> None:
+def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None) -> None:
     """``flashy.distrib.sync_model`` + ``optimizer.step()`` (bm/solver.py:386-387) on the flat bucket:
     reduce-scatter(grads) -> Adam on the own shard (mean over ranks via grad_scale) -> all-gather
-    (params)."""
+    (params); float buffers (BatchNorm running statistics) averaged with one all-reduce."""
     if not is_distributed():
         optimizer.step()
         return
-    world = world_size()
     shard = sync_flat_gradients(optimizer)
-    optimizer.step(shard=shard, grad_scale=1.0 / world)
-    lo, hi = shard
-    dist.all_gather_into_tensor(optimizer.flat_param, optimizer.flat_param[lo:hi].clone())
+    optimizer.step(shard=shard, grad_scale=1.0 / world_size())
+    _comm.all_gather_shards(optimizer.flat_param)
+    if buffers is not None:
+        buffers.average()
+
+
+class BufferBucket:
+    """All floating-point buffers of the models (BatchNorm running_mean / running_var) as views into ONE
+    flat tensor, so that flashy.distrib.sync_model's buffer averaging [upstream, unverified] is a
+    single in-place all-reduce + one scale instead of a cat / copy-back per step."""
+
+    def __init__(self, models: tp.Iterable[torch.nn.Module]):
+        self.buffers = [b for m in models for b in m.buffers() if b.is_floating_point()]
+        self.flat = None
+        if self.buffers:
+            dev = self.buffers[0].device
+            n = sum(b.numel() for b in self.buffers)
+            self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+            off = 0
+            for b in self.buffers:
+                k = b.numel()
+                self.flat[off:off + k].copy_(b.reshape(-1))
+                b.data = self.flat[off:off + k].view(b.shape)       # same tensor object, new storage
+                off += k
+
+    def average(self):
+        if self.flat is None or not is_distributed():
+            return
+        _comm.all_reduce(self.flat)
+        self.flat.mul_(1.0 / world_size())
 
 
 def sync_buffers(model: torch.nn.Module) -> None:
-    """flashy.distrib.sync_model also averages float buffers (BatchNorm running statistics)
-    [upstream, unverified]; one flat all-reduce."""
+    """One-off form of ``BufferBucket.average`` for a model whose buffers were not flattened."""
     if not is_distributed():
         return
     bufs = [b for b in model.buffers() if b.is_floating_point()]
     if not bufs:
         return
-    flat = torch.cat([b.reshape(-1) for b in bufs])
-    dist.all_reduce(flat)
+    flat = torch.cat([b.reshape(-1) for b in bufs]).float().contiguous()
+    _comm.all_reduce(flat)
     flat /= world_size()
     off = 0
     for b in bufs:
@@ -126,23 +340,45 @@ def average_metrics(metrics: tp.Dict[str, float], count: float = 1.) -> tp.Dict[
     if not is_distributed():
         return dict(metrics)
     keys = sorted(metrics)
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(metrics[k]) * count for k in keys] + [float(count)], device=dev,
-                     dtype=torch.float64 if dev == "cpu" else torch.float32)
-    dist.all_reduce(t)
+    t = torch.tensor([float(metrics[k]) * count for k in keys] + [float(count)],
+                     device=_comm.scalar_device(), dtype=torch.float32)
+    _comm.all_reduce(t)
+    t = t.double().cpu()
     return {k: (t[i] / t[-1]).item() for i, k in enumerate(keys)}
+
+
+def max_over_ranks(value: float) -> float:
+    """Used by bench.py: the step time of the slowest rank."""
+    if not is_distributed():
+        return value
+    t = torch.tensor([value], device=_comm.scalar_device(), dtype=torch.float32)
+    _comm.all_reduce(t, op="max")
+    return float(t.cpu())
+
+
+def check_equal_over_ranks(value: int, what: str) -> None:
+    """Raises when ``value`` differs between ranks (two tiny all-reduces: max(v) and max(-v))."""
+    if not is_distributed():
+        return
+    t = torch.tensor([float(value), -float(value)], device=_comm.scalar_device(), dtype=torch.float32)
+    _comm.all_reduce(t, op="max")
+    hi, lo = float(t[0].cpu()), -float(t[1].cpu())
+    if hi != lo:
+        raise RuntimeError(f"{what} differs between ranks ({lo:.0f} .. {hi:.0f}): whole-node negatives need the "
+                           "same number of segments on every rank")
 
 
 class CandidateGather:
     """Whole-node negatives: all-gather of the candidate features, overlapped with the forward.
 
     ``start(candidates)`` enqueues the all-gather on a side stream; ``wait()`` returns
-    ``(gathered [world*B, ...] in rank order, target_offset = rank*B)``."""
+    ``(gathered [world*B, ...] in rank order, target_offset = rank*B)``.  Every rank must bring the
+    same number of segments (the Solver refuses the configurations in which per-rank rejection
+    could break that, and ``BM_CHECK_RANKS=1`` verifies it with an extra tiny all-reduce)."""
 
     def __init__(self):
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._out = None
-        self._work = None
         self._B = 0
 
     def start(self, candidates: torch.Tensor):
@@ -151,16 +387,19 @@ class CandidateGather:
             return
         world = world_size()
         self._B = candidates.shape[0]
+        if os.environ.get("BM_CHECK_RANKS", "0") == "1":
+            check_equal_over_ranks(candidates.numel(), "candidate block size")
         candidates = candidates.contiguous()
         out = torch.empty((world * self._B,) + tuple(candidates.shape[1:]), device=candidates.device,
                           dtype=candidates.dtype)
         if self.stream is not None and candidates.is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                dist.all_gather_into_tensor(out, candidates)
+                _comm.all_gather(out, candidates)
             candidates.record_stream(self.stream)
+            out.record_stream(self.stream)
         else:
-            dist.all_gather_into_tensor(out, candidates)
+            _comm.all_gather(out, candidates)
         self._out = out
 
     def wait(self) -> tp.Tuple[torch.Tensor, int]:
@@ -185,19 +424,16 @@ class GatherCandidatesFn(torch.autograd.Function):
         candidates = candidates.contiguous()
         out = torch.empty((world * candidates.shape[0],) + tuple(candidates.shape[1:]),
                           device=candidates.device, dtype=candidates.dtype)
-        dist.all_gather_into_tensor(out, candidates)
+        _comm.all_gather(out, candidates)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        world, r = world_size(), rank()
+        world = world_size()
         grad = grad.contiguous()
         B = grad.shape[0] // world
-        if dist.get_backend() == "gloo":
-            dist.all_reduce(grad)
-            return grad[r * B:(r + 1) * B].clone()
         out = torch.empty((B,) + tuple(grad.shape[1:]), device=grad.device, dtype=grad.dtype)
-        dist.reduce_scatter_tensor(out, grad)
+        _comm.reduce_scatter(out, grad)
         return out
 
 

@@ -173,7 +173,7 @@ class SubjectLayersFn(torch.autograd.Function):
     def forward(ctx, x, weights, subjects):
         x, weights = _c(x), _c(weights)
         S, C, D = weights.shape
-        widx = subjects.to(torch.int32)
+        widx = H.index_i32(_c(subjects.to(torch.int64)), S)      # range-checked like the reference's gather
         wp = H.pack_weights(weights, S, D, C, 1, C * D, 1, D, 0)
         _, out, _ = H.conv_nn(x, wp, D, 1, 1, widx=widx)
         ctx.save_for_backward(x, weights, subjects, widx)
@@ -213,16 +213,16 @@ class ChannelMergerFn(torch.autograd.Function):
         scores = H.gemm_nt(heads, emb, U, O, C, D, a_strides=(0, D), x_strides=(C * D, D), seg=seg,
                            G=U, force_f32=True).view(U, O, C)
         weights = H.masked_softmax(scores, positions_u, ban_center, ban_radius)
-        widx = layout_index.to(torch.int32)
+        widx = H.index_i32(_c(layout_index.to(torch.int64)), U)
         wp = H.pack_weights(weights, U, O, C, 1, O * C, C, 1, 0)
         _, out, _ = H.conv_nn(meg, wp, O, 1, 1, widx=widx)
-        ctx.save_for_backward(meg, emb, weights, layout_index)
+        ctx.save_for_backward(meg, emb, weights, layout_index, widx)
         ctx.dims = (U, C, O, D)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        meg, emb, weights, layout_index = ctx.saved_tensors
+        meg, emb, weights, layout_index, widx = ctx.saved_tensors
         U, C, O, D = ctx.dims
         dout = _c(dout)
         B, _, T = meg.shape
@@ -238,7 +238,7 @@ class ChannelMergerFn(torch.autograd.Function):
         dmeg = None
         if ctx.needs_input_grad[0]:
             wpt = H.pack_weights(weights, U, C, O, 1, O * C, 1, C, 0)
-            _, dmeg, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=layout_index.to(torch.int32))
+            _, dmeg, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=widx)
         return dmeg, dheads, None, None, None, None
 
 

@@ -173,14 +173,55 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     return y_pre, y_out, stats
 
 
+# Device-side "index out of range" flag (one int32 per device).  The grouped kernels never read outside
+# their weight tables (bad indices are clamped to group 0 by bm_index_to_i32 / skipped by
+# bm_group_by_index); the flag is raised as an IndexError at the next synchronisation point the caller
+# chooses (`raise_if_index_error`, called by Solver next to the reference's isfinite asserts), or
+# immediately with BM_CHECK_INDICES=1.
+_index_err: tp.Dict[torch.device, torch.Tensor] = {}
+_CHECK_INDICES_NOW = _os.environ.get("BM_CHECK_INDICES", "0") == "1"
+
+
+def index_error_flag(device) -> torch.Tensor:
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    flag = _index_err.get(device)
+    if flag is None:
+        flag = torch.zeros(1, device=device, dtype=torch.int32)
+        _index_err[device] = flag
+    return flag
+
+
+def raise_if_index_error(device=None):
+    """Synchronising check of the flag; raises like the reference's out-of-range gather would."""
+    flags = list(_index_err.values()) if device is None else [index_error_flag(device)]
+    for flag in flags:
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError("subject / layout index out of range for the weight table "
+                             "(bm/models/common.py:57 would raise in `weights.gather`)")
+
+
+def index_i32(idx: torch.Tensor, G: int) -> torch.Tensor:
+    """idx [B] int64 -> int32 group indices, range-checked against [0, G) on the device."""
+    _req(idx, "index_i32.idx", torch.int64)
+    out = torch.empty(idx.numel(), device=idx.device, dtype=torch.int32)
+    check(lib().bm_index_to_i32(_p(idx), idx.numel(), G, _p(out), _p(index_error_flag(idx.device)),
+                                _stream()), "bm_index_to_i32")
+    if _CHECK_INDICES_NOW:
+        raise_if_index_error(idx.device)
+    return out
+
+
 def group_by_index(idx: torch.Tensor, G: int):
     """idx [B] int64 -> (order [B] int32, seg [G+1] int32)."""
     _req(idx, "group_by_index.idx", torch.int64)
     B = idx.numel()
     order = torch.empty(B, device=idx.device, dtype=torch.int32)
     seg = torch.empty(G + 1, device=idx.device, dtype=torch.int32)
-    check(lib().bm_group_by_index(_p(idx), B, G, _p(order), _p(seg), None, _stream()),
-          "bm_group_by_index")
+    check(lib().bm_group_by_index(_p(idx), B, G, _p(order), _p(seg), _p(index_error_flag(idx.device)),
+                                  _stream()), "bm_group_by_index")
     return order, seg
 
 

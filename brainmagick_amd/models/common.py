@@ -246,14 +246,14 @@ class PositionGetter:
         index: tp.List[int] = []
         for idx in range(len(batch)):
             rec = batch._recordings[idx]
-            key = rec.recording_index
-            if key not in slots:
-                slots[key] = len(rows)
+            rec_key = rec.recording_index
+            if rec_key not in slots:
+                slots[rec_key] = len(rows)
                 pos = torch.full((n_channels, 2), self.INVALID)
                 rec_pos = self.get_recording_layout(rec)
                 pos[:len(rec_pos)] = rec_pos
                 rows.append(pos)
-            index.append(slots[key])
+            index.append(slots[rec_key])
         positions_u = torch.stack(rows).to(device)
         layout_index = torch.tensor(index, dtype=torch.int64).to(device)
         if len(self._device_cache) >= 64:

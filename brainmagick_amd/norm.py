@@ -57,6 +57,26 @@ class DeviceBatchScaler:
         return dataclasses.replace(batch, meg=meg, features=features)
 
 
+def _subset(batch, keep: torch.Tensor):
+    """``batch[keep]`` with the reference's semantics (bm/dataset.py:242-257): tensor fields are
+    indexed, list fields (``_recordings``, ``_event_lists``) keep the selected items, empty lists stay
+    empty.  Uses the batch's own ``__getitem__`` when it has one (the reference's SegmentBatch)."""
+    if hasattr(type(batch), "__getitem__"):
+        return batch[keep]
+    idx = keep.nonzero().flatten()
+    picked = idx.tolist()
+    kw = {}
+    for field in dataclasses.fields(batch):
+        data = getattr(batch, field.name)
+        if isinstance(data, list):
+            kw[field.name] = [data[i] for i in picked] if data else []
+        elif isinstance(data, torch.Tensor):
+            kw[field.name] = data[idx]
+        else:
+            kw[field.name] = data
+    return dataclasses.replace(batch, **kw)
+
+
 class ScaleReject:
     """bm/norm.py:311-345.  Rescales MEG and features; rejects items whose scaled MEG still exceeds
     ``limit`` (or, with ``clip``, clamps instead).  With ``clip=True`` (conf/config.yaml:131) no
@@ -93,13 +113,7 @@ class ScaleReject:
         self._rejection_count += n_reject
         if n_reject == 0:
             return batch, keep
-        idx = keep.nonzero().flatten()
-        recs = [batch._recordings[i] for i in idx.tolist()]
-        batch = dataclasses.replace(
-            batch, meg=batch.meg[idx], features=batch.features[idx],
-            features_mask=batch.features_mask[idx], subject_index=batch.subject_index[idx],
-            recording_index=batch.recording_index[idx], _recordings=recs)
-        return batch, keep
+        return _subset(batch, keep), keep
 
     @property
     def rejection_rate(self):

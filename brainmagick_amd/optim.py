@@ -6,11 +6,16 @@ one (foreach) kernel chain; here all parameters and all gradients live in ONE fl
 
   * the optimiser is a single fused HIP launch (``bm_adam_step``), and
   * the data-parallel gradient exchange is one RCCL reduce-scatter + one all-gather on that bucket
-    (``distrib.sync_flat_gradients``) with each rank updating only its shard (ZeRO-1 style) --
+    (``distrib.sharded_step``) with each rank updating only its shard (ZeRO-1 style) --
     instead of flashy's per-tensor all-reduces (bm/solver.py:386).
 
-``state_dict`` / ``load_state_dict`` use torch.optim.Adam's layout (per-parameter ``step``,
-``exp_avg``, ``exp_avg_sq``) so optimizer checkpoints stay interchangeable with the reference.
+``FlatAdam`` is a ``torch.optim.Optimizer``: ``param_groups`` / ``state`` / ``state_dict`` /
+``load_state_dict`` / ``zero_grad`` / ``step`` behave like ``torch.optim.Adam``'s, so the reference's
+checkpoint code (bm/solver.py:64,115-117 -- ``self.optimizer.state_dict()`` goes into the flashy
+checkpoint) works unchanged and optimizer checkpoints are interchangeable with the reference:
+``state[p] = {step, exp_avg, exp_avg_sq}`` where the moments are VIEWS into the flat buffers.
+In a data-parallel run every rank only updates the moments of its own shard; ``state_dict()``
+all-gathers the shards first so that the checkpoint written by rank 0 is complete.
 """
 import typing as tp
 
@@ -19,17 +24,21 @@ import torch
 from . import hip_ops as H
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params: tp.Iterable[torch.nn.Parameter], lr: float = 3e-4,
                  betas: tp.Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, pad_to: int = 1):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError("FlatAdam got an empty parameter list")
-        dev = self.params[0].device
+        dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam runs on the MI355X HIP path only: move the model to the GPU "
                                "before building the optimizer (bm/train.py:89 does)")
-        self.lr, self.betas, self.eps = lr, betas, eps
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam supports a single parameter group (bm/train.py:118-119)")
+        self.params: tp.List[torch.nn.Parameter] = list(self.param_groups[0]["params"])
         n = sum(p.numel() for p in self.params)
         self.numel = n
         self.padded = (n + pad_to - 1) // pad_to * pad_to
@@ -47,37 +56,84 @@ class FlatAdam:
             self.offsets.append(off)
             off += k
         self.step_count = 0
+        self._step_tensor = torch.tensor(0.)
+        # a data-parallel step leaves the moments outside the own shard stale until gathered
+        self._moments_sharded = False
+        for p, off in zip(self.params, self.offsets):
+            k = p.numel()
+            self.state[p] = dict(step=self._step_tensor,
+                                 exp_avg=self.exp_avg[off:off + k].view(p.shape),
+                                 exp_avg_sq=self.exp_avg_sq[off:off + k].view(p.shape))
 
-    # -- torch.optim API subset used by the Solver (bm/solver.py:384-387) --
+    # the scalar hyper-parameters live in param_groups like in torch.optim.Adam (lr schedulers work)
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value: float):
+        self.param_groups[0]["lr"] = value
+
+    @property
+    def betas(self) -> tp.Tuple[float, float]:
+        return tuple(self.param_groups[0]["betas"])
+
+    @property
+    def eps(self) -> float:
+        return self.param_groups[0]["eps"]
+
+    # -- torch.optim API used by the Solver (bm/solver.py:384-387) --
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
-    def step(self, shard: tp.Optional[tp.Tuple[int, int]] = None, grad_scale: float = 1.0):
+    @torch.no_grad()
+    def step(self, closure=None, shard: tp.Optional[tp.Tuple[int, int]] = None,
+             grad_scale: float = 1.0):
         """Update the whole bucket, or only elements [lo, hi) when ``shard`` is given."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self.step_count += 1
+        self._step_tensor.fill_(float(self.step_count))
         lo, hi = shard if shard is not None else (0, self.padded)
+        if shard is not None and (lo, hi) != (0, self.padded):
+            self._moments_sharded = True
         if hi > lo:
+            b1, b2 = self.betas
             H.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi],
-                        self.exp_avg_sq[lo:hi], self.step_count, self.lr, self.betas[0],
-                        self.betas[1], self.eps, grad_scale)
+                        self.exp_avg_sq[lo:hi], self.step_count, self.lr, b1, b2, self.eps, grad_scale)
+        return loss
+
+    def gather_moments(self):
+        """Data-parallel runs: make ``exp_avg`` / ``exp_avg_sq`` complete on every rank (each rank
+        owns the moments of its shard only).  No-op for a single process."""
+        from . import distrib
+        if self._moments_sharded and distrib.is_distributed():
+            distrib.all_gather_shards(self.exp_avg)
+            distrib.all_gather_shards(self.exp_avg_sq)
+        self._moments_sharded = False
 
     def state_dict(self):
+        """torch.optim.Adam layout; moments are cloned (a checkpoint must not alias the live buckets)."""
+        self.gather_moments()
         state = {}
         for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             k = p.numel()
             state[i] = dict(step=torch.tensor(float(self.step_count)),
                             exp_avg=self.exp_avg[off:off + k].view(p.shape).clone(),
                             exp_avg_sq=self.exp_avg_sq[off:off + k].view(p.shape).clone())
-        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=0, amsgrad=False,
-                     params=list(range(len(self.params))))
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
         return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
         group = sd["param_groups"][0]
-        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        for key in ("lr", "betas", "eps"):
+            self.param_groups[0][key] = tuple(group[key]) if key == "betas" else group[key]
         for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             st = sd["state"].get(i)
             if st is None:
@@ -86,3 +142,5 @@ class FlatAdam:
             self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
             self.step_count = int(st["step"])
+        self._step_tensor.fill_(float(self.step_count))
+        self._moments_sharded = False      # every rank loaded the complete moments

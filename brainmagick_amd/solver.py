@@ -15,6 +15,7 @@ import typing as tp
 import torch
 
 from . import distrib
+from . import hip_ops as H
 from .losses import ClipLoss
 from .optim import FlatAdam
 
@@ -42,6 +43,15 @@ class Solver:
         self.negatives = negatives
         self._gather = distrib.CandidateGather() if negatives == "node" else None
         self.scale_reject = scale_reject          # brainmagick_amd.norm.ScaleReject or None
+        if negatives == "node" and scale_reject is not None and \
+                (not scale_reject.clip or scale_reject.exclude_empty_features):
+            # per-rank rejection would leave ranks with different numbers of segments: the candidate
+            # all-gather (equal blocks, target_offset = rank * B) cannot express that
+            raise ValueError('negatives="node" needs the same number of segments on every rank: use '
+                             'ScaleReject(clip=True, exclude_empty_features=False) (conf/config.yaml:131 '
+                             'norm.clip=true) or negatives="local"')
+        # flashy.distrib.sync_model also averages the float buffers (BatchNorm running statistics)
+        self._buffers = distrib.BufferBucket(self._all_models())
         self.check_finite = check_finite          # bm/solver.py:258-260 asserts (one fused host sync)
         self._last_batch = None
 
@@ -58,9 +68,15 @@ class Solver:
         if len(meg) == 0:
             return None, None, None, None
         if self.check_finite:
-            # bm/solver.py:258-260 (three separate asserts / syncs in the reference, one here)
-            assert bool(torch.isfinite(meg).all() & torch.isfinite(features).all()), \
-                "non-finite values in the MEG or feature tensors"
+            # bm/solver.py:258-260 (three separate asserts / syncs in the reference, one here); the same
+            # synchronisation point reports an out-of-range subject / layout index of the PREVIOUS step
+            # (the reference's `weights.gather` would have raised, bm/models/common.py:57)
+            finite = torch.isfinite(meg).all() & torch.isfinite(features).all()
+            flag = H.index_error_flag(meg.device)
+            finite_ok, index_err = torch.stack([finite.to(torch.int32), flag[0]]).tolist()   # ONE sync
+            assert finite_ok, "non-finite values in the MEG or feature tensors"
+            if index_err:
+                H.raise_if_index_error(meg.device)
         if self.offset_meg_ms:
             # bm/solver.py:262-274: brain responses lag the audio by ~150 ms
             offset = int(self.offset_meg_ms / 1000 * self.sample_rate)
@@ -108,7 +124,7 @@ class Solver:
         # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
         self.optimizer.zero_grad()
         loss.backward()
-        distrib.sharded_step(self.optimizer)
+        distrib.sharded_step(self.optimizer, self._buffers)
         return loss.detach()
 
     @torch.no_grad()

@@ -48,15 +48,33 @@ class SegmentBatch:
     features_mask: torch.Tensor   # [B, 1, T] bool
     subject_index: torch.Tensor   # [B] int64
     recording_index: torch.Tensor  # [B] int64
-    _recordings: tp.List[Recording]
+    _recordings: tp.List[Recording] = dataclasses.field(default_factory=list)
+    _event_lists: tp.List[tp.Any] = dataclasses.field(default_factory=list)
 
     def __len__(self) -> int:
         return len(self.meg)
 
     def to(self, device) -> "SegmentBatch":
-        return SegmentBatch(self.meg.to(device), self.features.to(device),
-                            self.features_mask.to(device), self.subject_index.to(device),
-                            self.recording_index.to(device), self._recordings)
+        kw = {}
+        for field in dataclasses.fields(self):
+            data = getattr(self, field.name)
+            kw[field.name] = data.to(device) if isinstance(data, torch.Tensor) else data
+        return SegmentBatch(**kw)
+
+    def replace(self, **kwargs) -> "SegmentBatch":
+        return dataclasses.replace(self, **kwargs)
+
+    def __getitem__(self, index) -> "SegmentBatch":
+        """bm/dataset.py:242-257: tensors are indexed, list fields keep the selected items."""
+        picked = torch.arange(len(self), device=self.meg.device)[index].tolist()
+        kw = {}
+        for field in dataclasses.fields(self):
+            data = getattr(self, field.name)
+            if isinstance(data, list):
+                kw[field.name] = [data[i] for i in picked] if data else []
+            else:
+                kw[field.name] = data[index]
+        return SegmentBatch(**kw)
 
     def positions(self) -> torch.Tensor:
         """What PositionGetter.get_positions returns (common.py:225-233): [B, C, 2], CPU."""

@@ -43,6 +43,9 @@ int bm_pack_weights(const float* src, float* dst, int G, int M, int Cin, int KS,
                     long sc, long sj, int flip, const float* alpha_ptr, void* stream);
 /* Stable grouping of segments by subject / layout index; replaces the gather at common.py:57. */
 int bm_group_by_index(const long* idx, int B, int G, int* order, int* seg, int* err_flag, void* stream);
+/* int64 -> int32 group indices with a range check: out-of-range entries set *err_flag (caller raises like
+ * the reference's `self.weights.gather(0, subjects...)`, bm/models/common.py:57) and are clamped to 0. */
+int bm_index_to_i32(const long* idx, int B, int G, int* out, int* err_flag, void* stream);
 int bm_reduce_splits(const float* part, float* out, int G, int nsplit, int M, int Cn, int KS, long sg,
                      long sm, long sc, long sj, void* stream);
 int bm_sum_over_batch(const float* x, float* out, int B, long n, void* stream);
@@ -170,6 +173,24 @@ int bm_segment_sum_cols(const float* p, const int* order, const int* seg, float*
 /* ---- fused Adam on the flat bucket (adam.hip)  torch.optim.Adam @ bm/train.py:118-119 ---- */
 int bm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
                  double lr, double beta1, double beta2, double eps, double grad_scale, void* stream);
+
+/* ---- data-parallel collectives: RCCL behind the C-ABI (comm.hip) ----
+ * Replace flashy.distrib.init (bm/train.py:139), flashy.distrib.sync_model (bm/solver.py:386: gradient
+ * mean = in-place reduce-scatter of the flat gradient bucket + Adam on the shard + in-place all-gather of
+ * the parameters; BatchNorm buffers by all-reduce), flashy.distrib.average_metrics (bm/solver.py:395), and
+ * add the whole-node candidate all-gather (README.md:139-143 keeps negatives per GPU).  One process per GPU.
+ * librccl is dlopen'ed on first use (BM_RCCL_LIB overrides the path).  The opaque handle is the only state
+ * the library owns; fp32 buffers; collectives are enqueued on `stream`, never synchronised; NCCL in-place
+ * conventions (all-gather: send == recv + rank*count; reduce-scatter: recv == send + rank*count). */
+int bm_comm_unique_id_bytes(void);
+int bm_comm_unique_id(void* out_id);                       /* rank 0; the host hands the bytes to the others */
+int bm_comm_init(const void* id, int world, int rank, int device, void** handle);
+int bm_comm_destroy(void* handle);
+int bm_comm_world(void* handle);
+int bm_comm_rank(void* handle);
+int bm_comm_allgather(void* handle, const float* send, float* recv, long count, void* stream);
+int bm_comm_reduce_scatter(void* handle, const float* send, float* recv, long count, void* stream);
+int bm_comm_allreduce(void* handle, const float* send, float* recv, long count, int op, void* stream);
 
 #ifdef __cplusplus
 }

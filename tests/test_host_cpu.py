@@ -157,6 +157,22 @@ assert abs(m["loss"] - (1 * 1 + 2 * 2) / 3) < 1e-9
 bn = torch.nn.BatchNorm1d(4); bn.running_mean.fill_(float(r))
 distrib.sync_buffers(bn)
 assert torch.allclose(bn.running_mean, torch.full((4,), 0.5))
+# flashy.sync_model's buffer averaging as ONE flat all-reduce (buffers become views of the bucket)
+bn2 = torch.nn.BatchNorm1d(3); bn2.running_var.fill_(float(2 * r + 1))
+bucket = distrib.BufferBucket([bn2])
+bucket.average()
+assert torch.allclose(bn2.running_var, torch.full((3,), 2.0)) and bn2.running_var.data_ptr() >= bucket.flat.data_ptr()
+# sharded optimizer moments: every rank owns shard r, a checkpoint needs all of them
+mom = torch.zeros(8); lo, hi = distrib.shard_bounds(8, w, r); mom[lo:hi] = r + 1.0
+distrib.all_gather_shards(mom)
+assert torch.equal(mom, torch.tensor([1.] * 4 + [2.] * 4)), mom
+assert abs(distrib.max_over_ranks(float(r)) - 1.0) < 1e-9
+distrib.check_equal_over_ranks(7, "same everywhere")
+try:
+    distrib.check_equal_over_ranks(7 + r, "differs")
+    raise SystemExit("check_equal_over_ranks did not raise")
+except RuntimeError:
+    pass
 # learnable candidates: autograd-aware all-gather, gradient reduce-scattered back to the owner
 x = torch.full((2, 3), float(r + 1), requires_grad=True)
 gathered, off = distrib.gather_learnable_candidates(x)
@@ -173,7 +189,7 @@ print("WORKER_OK", r)
 def test_data_parallel_exchange_world2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -210,3 +226,39 @@ def test_deep_mel_known_answer_of_the_reference():
     model = DeepMel(8, 3, 5, 2, kernel=3, stride=1, dilation_growth=2, dilation_period=5, batch_norm=True,
                     activation_on_last=False, skip=True, glu_context=1, glu=2)
     assert len(model.sequence) == 5
+
+
+def test_layout_device_cache_hits_on_the_second_call():
+    """the cache key was clobbered by the loop variable, so every step re-uploaded the layouts."""
+    from brainmagick_amd import synthetic
+    from brainmagick_amd.models.common import PositionGetter
+    batch = synthetic.make_batch(6, 10, 8, 4, 3, n_layouts=3)
+    getter = PositionGetter()
+    pos1, idx1 = getter.get_unique_layouts(batch, 10, "cpu")
+    pos2, idx2 = getter.get_unique_layouts(batch, 10, "cpu")
+    assert pos1 is pos2 and idx1 is idx2
+    assert len(getter._device_cache) == 1 and isinstance(next(iter(getter._device_cache)), tuple)
+    want = torch.stack([batch._recordings[i].layout for i in range(6)])
+    assert torch.equal(pos1[idx1], want)
+
+
+def test_scale_reject_subset_follows_the_reference_getitem():
+    """bm/dataset.py:242-257: batch[keep] subsets every list field and tolerates empty lists."""
+    import dataclasses
+    from brainmagick_amd import synthetic
+    from brainmagick_amd.norm import _subset
+    batch = synthetic.make_batch(5, 4, 8, 3, 2, n_layouts=2)
+    batch._event_lists = [[f"ev{i}"] for i in range(5)]
+    keep = torch.tensor([True, False, True, True, False])
+    sub = _subset(batch, keep)
+    assert len(sub) == 3 and sub._event_lists == [["ev0"], ["ev2"], ["ev3"]]
+    assert [r.recording_index for r in sub._recordings] == [batch._recordings[i].recording_index for i in (0, 2, 3)]
+    assert torch.equal(sub.meg, batch.meg[keep]) and torch.equal(sub.subject_index, batch.subject_index[keep])
+
+    @dataclasses.dataclass
+    class Plain:          # a batch type without __getitem__ and with empty optional lists
+        meg: torch.Tensor
+        features_mask: torch.Tensor
+        _recordings: list = dataclasses.field(default_factory=list)
+    plain = _subset(Plain(batch.meg, batch.features_mask), keep)
+    assert plain._recordings == [] and plain.meg.shape[0] == 3
