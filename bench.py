@@ -2,22 +2,35 @@
 """Headline benchmark of the MI355X-native SimpleConv + ClipLoss training step.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+With N > 1 and no torchrun environment the script re-launches itself as
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py``
+(one rank per GPU); launched under torchrun by the driver it uses the environment it finds.
 
 One "step" = the whole hot path on one synthetic batch already resident in HBM
 (bm/solver.py:343-390): SimpleConv forward, ClipLoss, backward, gradient exchange, fused Adam.
 Workload = BASELINE.json configs[1] (gwilliams2022-shaped MEG: 208 sensors x 360 samples, 120 mel
-features, 27 subjects, batch 256 per GPU, the paper's clip_conv model).  With N > 1 every rank
-processes its own 256 segments (weak scaling), candidates are all-gathered so the negatives pool is
-whole-node (configs[3]) and gradients go through ONE reduce-scatter + all-gather on the flat bucket.
+features, 27 subjects, batch 256 per GPU, the paper's clip_conv model).  The timed loop cycles through
+8 distinct batches per rank and draws a fresh segment -> recording assignment every step, so the
+per-step host work of a shuffled training stream (layout de-duplication, index upload) is inside the
+timed region.  With N > 1 every rank processes its own 256 segments (weak scaling), candidates are
+all-gathered so the negatives pool is whole-node (configs[3]) and gradients go through ONE in-place
+reduce-scatter + all-gather on the flat bucket, on RCCL behind the C-ABI (bm_comm_*).
 
-Rank 0 prints ONE JSON line with the driver's contract plus ``roofline`` (dominant kernel, timed
-live with HIP events on the launch stream inside the timed region) and ``cpu_baseline`` (the CPU
-oracle = torch-CPU restatement of the reference, timed on this host's cores on a bounded sample).
+Rank 0 prints ONE JSON line with the driver's contract plus
+  ``roofline``       dominant kernel, timed with HIP events on the launch stream in a second, untimed
+                     pass over the same batches right after the timed region (no event records inside
+                     the timed region);
+  ``roofline_clip``  the ClipLoss contraction (bm/losses.py:91-95) the same way, for cfg2 and cfg3 shapes;
+  ``cpu_baseline``   the CPU oracle (torch-CPU restatement of the reference path, kind "port": the
+                     reference modules themselves need /root/reference, absent on the GPU box) on cfg1
+                     (batch 16) with 1 thread (what bm/train.py:182 configures) and with all host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -42,8 +55,18 @@ CLIP_CONV = dict(depth=10, kernel_size=3, dilation_growth=2, dilation_period=5, 
                  subject_layers_dim="input", subject_dim=0)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA peak (opt-in --dtype bf16 mode only)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0     # dense bf16 / f16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+# MFMA products per fp32-accurate block of each compute mode -> fp32-equivalent peak = 16-bit peak / products
+MODE_PEAK_TFLOPS = {"f32": PEAK_FP32_MFMA_TFLOPS, "f32x3": PEAK_16BIT_MFMA_TFLOPS / 6.0,
+                    "f16x2": PEAK_16BIT_MFMA_TFLOPS / 3.0, "bf16": PEAK_16BIT_MFMA_TFLOPS}
+MODE_DTYPE = {
+    "f16x2": "f32 (fp32-accurate: operands split into 2 scaled f16 planes, 3 MFMA products, fp32 accumulate; "
+             "same parity tolerances as exact fp32, see DESIGN.md §2)",
+    "f32x3": "f32 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 MFMA products, "
+             "fp32 accumulate; error vs fp64 <= exact-fp32 MFMA, see DESIGN.md §2)",
+    "f32": "f32 (exact-fp32 MFMA)",
+    "bf16": "bf16 operands, f32 accumulate (REDUCED precision, information only)"}
 
 
 def algorithmic_flops_per_segment(C, T, F, hidden=320, merger_ch=270) -> float:
@@ -58,6 +81,12 @@ def algorithmic_flops_per_segment(C, T, F, hidden=320, merger_ch=270) -> float:
             mac += 2 * hidden * hidden * 3 * T    # GLU conv
     mac += 2 * hidden * hidden * T + 2 * hidden * F * T   # head
     return 2.0 * 3.0 * mac
+
+
+def algorithmic_bytes_per_step(C, T, F, B, n_params, hidden=320, merger_ch=270) -> float:
+    """4*(C*T + 5*A) bytes per segment + 12 bytes per parameter per step."""
+    A = merger_ch * T * 3 + hidden * T * 10 + 2 * hidden * T * 5 + hidden * T * 5 + 2 * hidden * T + F * T
+    return B * 4.0 * (C * T + 5 * A) + 12.0 * n_params
 
 
 def pmc_traffic(kernel_label: str):
@@ -75,41 +104,54 @@ def pmc_traffic(kernel_label: str):
     return None, files[-1].name
 
 
-def cpu_baseline(workload, seconds_budget=20.0):
-    """The CPU oracle (port of the reference path) timed on the host cores, bounded sample."""
+def cpu_baseline(seconds_budget=14.0):
+    """The CPU oracle (port of the reference path) on cfg1 = BASELINE.json configs[0] (fake-study shaped,
+    batch 16), timed with 1 thread (bm/train.py:182) and with all host cores, bounded samples."""
     from oracle import bm_oracle as O
-    B = 16
-    c = synthetic.CONFIGS[workload]
-    sb = synthetic.make_batch(B, c["C"], c["T"], c["F"], c["S"], seed=2036)
+    c = synthetic.CONFIGS["cfg1"]
+    B = c["B"]
+    sb = synthetic.make_config_batch("cfg1", seed=2036)
     torch.manual_seed(0)
     model = SimpleConv(in_channels={"meg": c["C"]}, out_channels=c["F"], hidden={"meg": 320},
                        n_subjects=c["S"], **CLIP_CONV)
-    oracle = O.OracleModel(model.state_dict(), O.CLIP_CONV_CFG, 320, c["F"])
+    sd = model.state_dict()
     ban = torch.tensor([0.5, 0.5])
     pos = sb.positions()
-    times = []
-    t_start = time.perf_counter()
-    steps = 0
-    while steps < 2 or (time.perf_counter() - t_start < seconds_budget and steps < 12):
-        t0 = time.perf_counter()
-        oracle.train_step(sb.meg, pos, sb.subject_index, sb.features, ban)
-        times.append(time.perf_counter() - t0)
-        steps += 1
-    timed = sorted(times[1:])
-    med = timed[len(timed) // 2]
-    return dict(value=B / med, unit="segments/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{len(timed)} train steps of batch {B} ({workload} shapes), median step "
-                       f"{med * 1e3:.0f} ms, torch CPU fp32")
+    prev = torch.get_num_threads()
+    ncores = os.cpu_count() or prev
+    out = {}
+    for label, n in (("all_cores", ncores), ("one_thread", 1)):
+        torch.set_num_threads(n)
+        oracle = O.OracleModel({k: v.clone() for k, v in sd.items()}, O.CLIP_CONV_CFG, 320, c["F"])
+        times, losses = [], []
+        t_start = time.perf_counter()
+        while len(times) < 2 or (time.perf_counter() - t_start < seconds_budget and len(times) < 7):
+            t0 = time.perf_counter()
+            losses.append(float(oracle.train_step(sb.meg, pos, sb.subject_index, sb.features, ban)[0]))
+            times.append(time.perf_counter() - t0)
+        timed = sorted(times[1:])
+        med = timed[len(timed) // 2]
+        out[label] = dict(value=B / med, unit="segments/s", cores=n, median_step_ms=med * 1e3,
+                          steps_timed=len(timed), first_loss=losses[0])
+    torch.set_num_threads(prev)
+    best = max(out.values(), key=lambda r: r["value"])
+    return dict(value=best["value"], unit="segments/s", cores=best["cores"], kind="port",
+                sample=f"cfg1 (C=273 T=360 F=120, batch {B}), clip_conv model, whole training step "
+                       f"(forward + ClipLoss + backward + Adam), torch CPU fp32, median of "
+                       f"{best['steps_timed']} steps after 1 warm-up; CPU oracle = restatement of the reference "
+                       "path (the reference modules need /root/reference, absent on the GPU box)",
+                one_thread=out["one_thread"], all_cores=out["all_cores"], host_cores=ncores)
 
 
-def retrieval_block(workload, B, steps, dev, n_train=8, n_held=4):
+def retrieval_block(workload, B, steps, dev, n_train=16, n_held=4, noise=1.5):
     """top-k segment retrieval (scripts/run_eval_probs.py:237-264 rule) of the full-size model after `steps`
     training steps on planted-latent synthetic batches, evaluated on held-out segments of the
-    same synthetic world.  Chance level for top-10 is 10 / (n_held * B)."""
+    same synthetic world.  Chance level for top-10 is 10 / (n_held * B).  The planted noise keeps the
+    task away from saturation."""
     from brainmagick_amd import retrieval
     from brainmagick_amd.losses import ClipLoss
     c = synthetic.CONFIGS[workload]
-    kw = dict(planted=True)
+    kw = dict(planted=True, noise=noise)
     if workload == "cfg5":
         kw["mixed_eeg"] = True
     torch.manual_seed(77)
@@ -128,8 +170,132 @@ def retrieval_block(workload, B, steps, dev, n_train=8, n_held=4):
     acc = retrieval.segment_topk_accuracy(ClipLoss().to(dev), torch.cat(ests), torch.cat(cands), topks=(1, 10))
     n = n_held * B
     return {"top1": acc["top1"], "top10": acc["top10"], "chance_top10": 10.0 / n, "held_out_segments": n,
-            "train_steps": steps, "train_batches": n_train, "first_loss": losses[0], "last_loss": losses[-1],
+            "train_steps": steps, "train_batches": n_train, "planted_noise": noise,
+            "first_loss": losses[0], "last_loss": losses[-1],
             "data": "planted-latent synthetic world (brainmagick_amd/synthetic.py), default compute mode"}
+
+
+def retrieval_parity_block(dev, steps=120, noise=0.8):
+    """HIP path and CPU oracle trained side by side (same initial state, same planted batches, reduced
+    model so that the oracle finishes in seconds): top-10 / top-1 retrieval on 1 024 held-out segments."""
+    import copy
+    from oracle import bm_oracle as O
+    from brainmagick_amd import retrieval
+    from brainmagick_amd.losses import ClipLoss
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=32, initial_linear=32, depth=6, merger_dropout=0.0)
+    C, T, Fd, S, B, hidden, n_batches, n_held = 24, 96, 16, 4, 32, 48, 32, 1024
+    torch.manual_seed(5)
+    model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, hidden, Fd)
+    solver = Solver(model, device=str(dev))
+    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True, noise=noise)
+               for i in range(n_batches)]
+    worst = 0.0
+    for step in range(steps):
+        sb = batches[step % n_batches]
+        lh = float(solver.train_step(sb))
+        lr_ = float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index, sb.features)[0])
+        worst = max(worst, abs(lh - lr_) / abs(lr_))
+    held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
+    est_hip, cand = solver.predict(held)
+    acc_hip = retrieval.segment_topk_accuracy(ClipLoss().to(dev), est_hip, cand, topks=(1, 10))
+    probs_ref = O.clip_probabilities(oracle.forward(held.meg, held.positions(), held.subject_index), held.features)
+    labels = torch.arange(n_held)
+    return {"hip_top10": acc_hip["top10"], "oracle_top10": O.topk_accuracy(probs_ref, labels, labels, 10),
+            "hip_top1": acc_hip["top1"], "oracle_top1": O.topk_accuracy(probs_ref, labels, labels, 1),
+            "max_rel_loss_gap": worst, "train_steps": steps, "held_out_segments": n_held,
+            "planted_noise": noise, "model": "clip_conv reduced (hidden 48, depth 6, C=24, T=96, F=16), batch 32"}
+
+
+def clip_roofline(dev, mode, reps=20):
+    """The contrastive contraction scores = est . cand^T over K = F*T (bm/losses.py:91-95) at batch 256 for the
+    cfg2 (F=120) and cfg3 (F=1024) shapes: HIP-event time of the whole forward (candidate norms are NOT
+    included: constant candidates; scores GEMM + split fold + row softmax / CE) and of the scores kernel alone."""
+    from brainmagick_amd import functional as BF
+    out = {}
+    for name, F in (("cfg2", 120), ("cfg3", 1024)):
+        B, T = 256, 360
+        K = F * T
+        g = torch.Generator(device="cpu").manual_seed(3)
+        est = torch.randn(B, F, T, generator=g).to(dev)
+        cand = torch.randn(B, F, T, generator=g).to(dev)
+        inv = hip_ops.clip_inv_norms(cand)
+        for _ in range(3):
+            BF.clip_forward_timed(est, cand, inv, None)
+        timer = hip_ops.KernelTimer()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            BF.clip_forward_timed(est, cand, inv, None)
+        ev1.record()
+        torch.cuda.synchronize()
+        fwd_us = ev0.elapsed_time(ev1) / reps * 1e3
+        for _ in range(reps):
+            BF.clip_forward_timed(est, cand, inv, timer)
+        torch.cuda.synchronize()
+        ks = timer.summary()
+        kname = max(ks, key=lambda k: ks[k]["avg_ms"])
+        t = ks[kname]["avg_ms"] * 1e-3
+        flops = 2.0 * B * B * K
+        nbytes = 4.0 * (B + B) * K
+        peak = MODE_PEAK_TFLOPS[mode]
+        mfma_frac = flops / t / 1e12 / peak
+        hbm_frac = nbytes / t / 1e9 / PEAK_HBM_GBS
+        out[name] = {"kernel": kname, "K": K, "kernel_us": t * 1e6, "forward_us": fwd_us,
+                     "achieved_tflops": flops / t / 1e12, "peak_tflops": peak, "mfma_frac": mfma_frac,
+                     "achieved_gbs": nbytes / t / 1e9, "peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_frac,
+                     "bound": "mfma" if mfma_frac >= hbm_frac else "hbm", "frac": max(mfma_frac, hbm_frac)}
+    return out
+
+
+def self_launch(args) -> int:
+    """python bench.py --gpus N without a torchrun environment: re-launch under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.call(cmd, env=env)
+
+
+class BatchStream:
+    """`n` distinct batches resident in HBM; every step gets the next one with a FRESH draw of the
+    segment -> recording assignment (host side), like a shuffled training stream would produce."""
+
+    def __init__(self, workload, B, rank, dev, n=8, n_recordings=16, n_draws=64):
+        c = synthetic.CONFIGS[workload]
+        gen = torch.Generator().manual_seed(4242)
+        if workload == "cfg5":
+            layouts = [torch.rand(c["C"], 2, generator=gen), torch.rand(128, 2, generator=gen)]
+            self.pool = [synthetic.Recording(i, layouts[i % 2].clone()) for i in range(n_recordings)]
+        else:       # one sensor layout shared by every recording of the study (gwilliams2022: one MEG system)
+            base = torch.rand(c["C"], 2, generator=gen)
+            self.pool = [synthetic.Recording(i, base.clone()) for i in range(n_recordings)]
+        self.batches = []
+        for i in range(n):
+            sb = synthetic.make_batch(B, c["C"], c["T"], c["F"], c["S"], seed=2036 + 1000 * rank + i,
+                                      recordings=self.pool, mixed_eeg=workload == "cfg5")
+            self.batches.append(sb.to(dev))
+        # fresh assignments that keep each segment on a recording of its own layout class
+        g2 = torch.Generator().manual_seed(99 + rank)
+        self.draws = []
+        for d in range(n_draws):
+            sb = self.batches[d % n]
+            recs = []
+            for r in sb._recordings:
+                same = [q for q in self.pool if len(q.layout) == len(r.layout)]
+                recs.append(same[int(torch.randint(0, len(same), (1,), generator=g2))])
+            self.draws.append(recs)
+        self.n = n
+        self.step = 0
+
+    def next(self):
+        sb = self.batches[self.step % self.n]
+        recs = self.draws[self.step % len(self.draws)]
+        self.step += 1
+        return sb.replace(_recordings=recs)
 
 
 def main():
@@ -146,19 +312,21 @@ def main():
                          "model this many steps on planted-signal synthetic batches and report top-1/top-10 "
                          "segment retrieval on held-out segments (single-GPU runs only; 0 disables)")
     ap.add_argument("--no-exact", action="store_true",
-                    help="skip the extra exact-fp32 MFMA timing block (profiling runs)")
-    ap.add_argument("--dtype", default="f32x3", choices=["f32x3", "f32", "bf16"],
-                    help="compute mode of the contractions. f32x3 (default): fp32-accurate 3xbf16-split "
-                         "emulation on the bf16 matrix cores (same parity tolerances as exact fp32); f32: "
-                         "exact-fp32 MFMA; bf16: opt-in REDUCED precision, for information only")
+                    help="skip the extra timing blocks of the other fp32-class modes (profiling runs)")
+    ap.add_argument("--no-clip", action="store_true", help="skip the ClipLoss contraction roofline block")
+    ap.add_argument("--dtype", default=hip_ops.DEFAULT_COMPUTE_DTYPE, choices=sorted(MODE_PEAK_TFLOPS),
+                    help="compute mode of the contractions; every fp32-class mode (f16x2, f32x3, f32) is held to the "
+                         "same parity tolerances; bf16 is opt-in REDUCED precision, for information only")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     hip_ops.set_compute_dtype(args.dtype)
     distrib.init()
     rank, world = distrib.rank(), distrib.world_size()
     if world != args.gpus:
-        if args.gpus != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -171,50 +339,45 @@ def main():
                        n_subjects=c["S"], **CLIP_CONV)
     n_params = sum(p.numel() for p in model.parameters())
     solver = Solver(model, device=str(dev), negatives=negatives)
-    batch = synthetic.make_config_batch(args.workload, seed=2036 + rank, batch=B).to(dev)
+    stream = BatchStream(args.workload, B, rank, dev)
+
+    def timed_steps(k):
+        distrib.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            loss = solver.train_step(stream.next())
+        distrib.barrier()
+        torch.cuda.synchronize()
+        return distrib.max_over_ranks(time.perf_counter() - t0), loss
 
     for _ in range(args.warmup):
-        solver.train_step(batch)
-    timer = hip_ops.KernelTimer()
-    distrib.barrier()
-    torch.cuda.synchronize()
-    hip_ops.set_kernel_timer(timer)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = solver.train_step(batch)
-    distrib.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    hip_ops.set_kernel_timer(None)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
+        solver.train_step(stream.next())
+    elapsed, loss = timed_steps(args.steps)
     final_loss = float(loss)
 
-    # For transparency the same job is also timed in the exact-fp32 MFMA mode (not part of `value`).
-    exact = None
-    if args.dtype == "f32x3" and not args.no_exact:
-        hip_ops.set_compute_dtype("f32")
-        k2 = max(2, args.steps // 4)
-        solver.train_step(batch)
-        distrib.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            solver.train_step(batch)
-        distrib.barrier()
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([e2], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            e2 = float(t)
-        exact = {"compute_mode": "f32 (exact-fp32 MFMA v_mfma_f32_32x32x2_f32)", "steps": k2,
-                 "ms_per_step": e2 / k2 * 1e3, "value": world * B * k2 / e2, "unit": "segments/s"}
+    # second pass over the same stream with per-launch HIP events (NOT part of `value`)
+    timer = hip_ops.KernelTimer()
+    hip_ops.set_kernel_timer(timer)
+    event_pass_elapsed, _ = timed_steps(args.steps)
+    hip_ops.set_kernel_timer(None)
+
+    # For transparency the same job is also timed in the other fp32-class modes (not part of `value`).
+    other_modes = {}
+    if not args.no_exact and args.dtype in ("f16x2", "f32x3"):
+        for mode in ("f16x2", "f32x3", "f32"):
+            if mode == args.dtype:
+                continue
+            hip_ops.set_compute_dtype(mode)
+            k2 = max(2, args.steps // 4)
+            solver.train_step(stream.next())
+            e2, _ = timed_steps(k2)
+            other_modes[mode] = {"compute_mode": mode, "steps": k2, "ms_per_step": e2 / k2 * 1e3,
+                                 "value": world * B * k2 / e2, "unit": "segments/s"}
         hip_ops.set_compute_dtype(args.dtype)
 
     if rank != 0:
+        distrib.barrier()
         return
     ksum = timer.summary()
     dom = max(ksum, key=lambda k: ksum[k]["avg_ms"] * ksum[k]["launches"])
@@ -222,11 +385,9 @@ def main():
     achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
     seg_flops = algorithmic_flops_per_segment(c["C"], c["T"], c["F"])
     traffic, traffic_src = pmc_traffic(dom)
-    # f32: exact-fp32 MFMA peak.  f32x3: six bf16 MFMAs per fp32-accurate block -> the algorithmic
-    # (fp32-equivalent) FLOP/s are priced against 1/6 of the dense bf16 peak.  bf16: dense bf16 peak.
-    peak_tf = {"f32": PEAK_FP32_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0,
-               "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
+    peak_tf = MODE_PEAK_TFLOPS[args.dtype]
     total_kernel_ms = sum(v["avg_ms"] * v["launches"] for v in ksum.values()) / args.steps
+    step_bytes = algorithmic_bytes_per_step(c["C"], c["T"], c["F"], B, n_params)
     out = {
         "metric": "segments/s, 208-ch x 360-sample SimpleConv + ClipLoss training step",
         "value": world * B * args.steps / elapsed,
@@ -234,16 +395,14 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32x3": "f32 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 MFMA products, "
-                           "fp32 accumulate; error vs fp64 <= exact-fp32 MFMA, see DESIGN.md §2)",
-                  "f32": "f32 (exact-fp32 MFMA)", "bf16": "bf16 operands, f32 accumulate (REDUCED "
-                                                          "precision, information only)"}[args.dtype],
+        "dtype": MODE_DTYPE[args.dtype],
         "compute_mode": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: gwilliams2022-shaped MEG C={c['C']} T={c['T']}, "
                                f"F={c['F']} features, {c['S']} subjects, clip_conv SimpleConv "
                                f"({n_params} params) + ClipLoss + Adam",
                    "batch_per_gpu": B, "global_batch": world * B, "negatives": negatives,
-                   "parallelism": f"dp{world}", "final_loss": final_loss,
+                   "parallelism": f"dp{world}", "comm": distrib.comm_kind(), "rccl_world": world,
+                   "distinct_batches": stream.n, "final_loss": final_loss,
                    "step_tflops": seg_flops * B * world * args.steps / elapsed / 1e12},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                      "peak": peak_tf, "unit": "TFLOP/s", "frac": achieved / peak_tf,
@@ -253,26 +412,41 @@ def main():
                      "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,
                      "algorithmic_flops_per_launch": d["flops_per_launch"],
                      "mfma_kernels_ms_per_step": total_kernel_ms,
-                     "hbm_roofline_frac_step": (B * 69.2e6 + 108e6) / (PEAK_HBM_GBS * 1e9)
-                     / (elapsed / args.steps) if args.workload == "cfg2" else None},
+                     "event_pass_ms_per_step": event_pass_elapsed / args.steps * 1e3,
+                     "per_kernel_ms_per_step": {k: v["avg_ms"] * v["launches"] / args.steps for k, v in
+                                                sorted(ksum.items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["launches"])},
+                     "hbm_roofline_frac_step": step_bytes / (PEAK_HBM_GBS * 1e9) / (elapsed / args.steps),
+                     "algorithmic_bytes_per_step": step_bytes},
     }
-    out["exact_f32_mfma"] = exact
+    out["other_fp32_modes"] = other_modes or None
+    out["exact_f32_mfma"] = other_modes.get("f32")
+    out["roofline_clip"] = None
+    if not args.no_clip:
+        try:
+            out["roofline_clip"] = clip_roofline(dev, args.dtype)
+        except Exception as exc:
+            out["roofline_clip"] = {"error": repr(exc)}
     out["retrieval"] = None
+    out["retrieval_parity"] = None
     if world == 1 and args.accuracy_steps > 0:
         try:
             out["retrieval"] = retrieval_block(args.workload, B, args.accuracy_steps, dev)
         except Exception as exc:   # the throughput line must survive a failure of the side measurement
             out["retrieval"] = {"error": repr(exc)}
+        try:
+            out["retrieval_parity"] = retrieval_parity_block(dev)
+        except Exception as exc:
+            out["retrieval_parity"] = {"error": repr(exc)}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload)
+        out["cpu_baseline"] = cpu_baseline()
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    distrib.barrier()
 
 
 if __name__ == "__main__":
     try:
         main()
     finally:
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
+        distrib.shutdown()

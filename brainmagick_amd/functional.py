@@ -298,3 +298,16 @@ def clip_scores(estimate, candidate, want_probs=False):
     part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
     scores, probs, _, _ = H.clip_ce(part, inv, want_probs=want_probs)
     return probs if want_probs else scores
+
+
+def clip_forward_timed(estimate, candidate, inv, timer):
+    """bench.py: the ClipLoss forward (scores contraction + split fold + row softmax / CE + dScores) on
+    precomputed candidate norms, optionally with per-kernel HIP events."""
+    B, Bc = estimate.shape[0], candidate.shape[0]
+    K = estimate.numel() // B
+    H.set_kernel_timer(timer)
+    try:
+        part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+        return H.clip_ce(part, inv, want_grad=True, want_loss=True)
+    finally:
+        H.set_kernel_timer(None)

@@ -22,7 +22,8 @@ BKC = 16
 #   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
 #   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
-_compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", "f32x3")
+DEFAULT_COMPUTE_DTYPE = "f32x3"
+_compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE)
 if _compute_dtype not in ("f32", "f32x3", "bf16"):
     raise ValueError(f"BM_COMPUTE_DTYPE must be f32, f32x3 or bf16, got {_compute_dtype!r}")
 
@@ -286,8 +287,15 @@ def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
     part = torch.empty(nsplit, M, Cn, device=a.device, dtype=torch.float32)
     # scores feed a softmax: exact fp32 or the fp32-accurate x3 path, never plain bf16
     fn = lib().bm_gemm_nt_x3 if _compute_dtype == "f32x3" else lib().bm_gemm_nt
-    check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1], None, None, _p(part),
-             S, 1, M, Cn, T, 1, 1, nsplit, _stream()), "bm_gemm_nt")
+
+    def launch():
+        check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1], None, None, _p(part),
+                 S, 1, M, Cn, T, 1, 1, nsplit, _stream()), "bm_gemm_nt")
+    if _timer is not None:
+        _timer.launch("clip_scores:gemm_nt" + ("_x3" if _compute_dtype == "f32x3" else ""),
+                      2.0 * S * T * M * Cn, launch)
+    else:
+        launch()
     return part
 
 

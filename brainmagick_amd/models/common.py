@@ -191,6 +191,9 @@ class PositionGetter:
         self._cache: tp.Dict[int, torch.Tensor] = {}
         self._invalid_names: tp.Set[str] = set()
         self._device_cache: tp.Dict[tp.Any, tp.Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._layout_set_cache: tp.Dict[tp.Any, torch.Tensor] = {}
+        self._layout_ids: tp.Dict[int, int] = {}          # recording_index -> id of its layout content
+        self._layout_bytes: tp.Dict[bytes, int] = {}
 
     def get_recording_layout(self, recording) -> torch.Tensor:
         index = recording.recording_index
@@ -234,27 +237,42 @@ class PositionGetter:
     def get_unique_layouts(self, batch, n_channels: int, device):
         """-> (positions_u [U, C, 2] on device, layout_index [B] int64 on device).
 
-        The device tensors are cached per (recording-index tuple, C, device): a training loop that
-        revisits the same recordings does not re-upload layouts every step."""
-        key = (tuple(batch._recordings[i].recording_index for i in range(len(batch))), n_channels,
-               str(device))
+        Two cache levels keep a shuffled training stream cheap: the stacked layouts of a SET of
+        recordings (in first-seen order) stay on the device, so a new batch over known recordings costs
+        one host loop over its segments and one 8*B-byte upload of the index; a batch that repeats a
+        previous segment->recording assignment exactly also re-uses the uploaded index."""
+        rec_ids = tuple(batch._recordings[i].recording_index for i in range(len(batch)))
+        key = (rec_ids, n_channels, str(device))
         hit = self._device_cache.get(key)
         if hit is not None:
             return hit
+        # recordings with byte-identical layouts (all sessions of one MEG system) share a slot
         slots: tp.Dict[int, int] = {}
-        rows: tp.List[torch.Tensor] = []
+        first: tp.List[int] = []
         index: tp.List[int] = []
-        for idx in range(len(batch)):
-            rec = batch._recordings[idx]
-            rec_key = rec.recording_index
-            if rec_key not in slots:
-                slots[rec_key] = len(rows)
+        for idx, rec_id in enumerate(rec_ids):
+            rec_key = self._layout_ids.get(rec_id)
+            if rec_key is None:
+                raw = self.get_recording_layout(batch._recordings[idx]).contiguous().numpy().tobytes()
+                rec_key = self._layout_ids[rec_id] = self._layout_bytes.setdefault(raw, len(self._layout_bytes))
+            slot = slots.get(rec_key)
+            if slot is None:
+                slot = slots[rec_key] = len(first)
+                first.append(idx)
+            index.append(slot)
+        set_key = (tuple(slots), n_channels, str(device))
+        positions_u = self._layout_set_cache.get(set_key)
+        if positions_u is None:
+            rows = []
+            for idx in first:
                 pos = torch.full((n_channels, 2), self.INVALID)
-                rec_pos = self.get_recording_layout(rec)
+                rec_pos = self.get_recording_layout(batch._recordings[idx])
                 pos[:len(rec_pos)] = rec_pos
                 rows.append(pos)
-            index.append(slots[rec_key])
-        positions_u = torch.stack(rows).to(device)
+            positions_u = torch.stack(rows).to(device)
+            if len(self._layout_set_cache) >= 64:
+                self._layout_set_cache.pop(next(iter(self._layout_set_cache)))
+            self._layout_set_cache[set_key] = positions_u
         layout_index = torch.tensor(index, dtype=torch.int64).to(device)
         if len(self._device_cache) >= 64:
             self._device_cache.pop(next(iter(self._device_cache)))

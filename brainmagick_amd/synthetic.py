@@ -94,13 +94,15 @@ def make_layouts(n_layouts: int, n_channels: tp.Sequence[int], gen: torch.Genera
 def make_batch(B: int, C: int, T: int, F: int, S: int, seed: int = 2036, n_layouts: int = 1,
                mixed_eeg: bool = False, planted: bool = False,
                recordings: tp.Optional[tp.List[Recording]] = None,
-               world_seed: int = 1234) -> SegmentBatch:
+               world_seed: int = 1234, noise: float = 0.5) -> SegmentBatch:
     """Seed 2036 = conf/config.yaml:33.  ``mixed_eeg`` reproduces cfg5: each sample is either a
     273-sensor MEG recording or a 128-sensor EEG recording zero-padded to C (dataset.py:353-354),
     EEG subjects 0..18 and MEG subjects 19..S-1.  ``planted`` adds a shared latent so that the
     contrastive task is learnable (used for the loss-curve / top-10 parity runs); the mixing
     matrices and the sensor layouts of the planted "world" only depend on ``world_seed`` so that
-    train and held-out batches (different ``seed``) share them."""
+    train and held-out batches (different ``seed``) share them; ``noise`` is the standard deviation of
+    the additive sensor / feature noise (0.5 = easy task, larger values push the retrieval accuracy
+    away from saturation)."""
     gen = torch.Generator().manual_seed(seed)
     if recordings is None and planted:
         wgen = torch.Generator().manual_seed(world_seed + 1)
@@ -125,9 +127,9 @@ def make_batch(B: int, C: int, T: int, F: int, S: int, seed: int = 2036, n_layou
         wgen = torch.Generator().manual_seed(world_seed)
         A = torch.randn(S, C, L, generator=wgen) / L ** 0.5
         W = torch.randn(F, L, generator=wgen)
-        meg = torch.einsum("bcl,blt->bct", A[subj], z) + 0.5 * torch.randn(B, C, T, generator=gen)
+        meg = torch.einsum("bcl,blt->bct", A[subj], z) + noise * torch.randn(B, C, T, generator=gen)
         feats = torch.einsum("fl,blt->bft", W, torch.roll(z, 18, dims=2)) \
-            + 0.5 * torch.randn(B, F, T, generator=gen)
+            + noise * torch.randn(B, F, T, generator=gen)
         meg = meg / meg.std()
         feats = (feats - feats.mean()) / feats.std()
     else:

@@ -222,6 +222,125 @@ def test_paper_model_step_against_oracle(cfg_name, B, T):
             assert running_stat_close(v, oracle.sd[k], 2), k
 
 
+@pytest.mark.parametrize("cfg_name,B", [("cfg2", 256), ("cfg3", 256), ("cfg5", 64)])
+def test_full_size_step_against_oracle(cfg_name, B):
+    """BASELINE.json configs[1] / configs[2] at their FULL size (batch 256, F = 120 / 1024) and the mixed
+    MEG/EEG config (273 sensors, 115 subjects, two layouts) at batch 64: loss, estimate and every
+    gradient of one training step against the CPU oracle (the oracle needs ~15 s per config on the GPU
+    box's host cores).  Same tolerances as the reduced-size tests, except the 1-D parameters (biases,
+    BatchNorm affine): their gradients are plain sums over B*T = 92 160 samples, where the fp32
+    oracle's own summation order is worth ~2e-4 (measured round 1: 1.7e-4 on final.2.bias)."""
+    from brainmagick_amd.solver import Solver
+    c = synthetic.CONFIGS[cfg_name]
+    sb = synthetic.make_config_batch(cfg_name, seed=2036, batch=B)
+    model = _paper_model(c["C"], c["F"], c["S"], seed=2036)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), O.CLIP_CONV_CFG, 320, c["F"])
+    ban = torch.tensor([0.4, 0.6])
+    model.merger.ban_center_override = ban
+    solver = Solver(model)
+    loss = solver.train_step(sb)
+    est = solver.predict(sb)[0]            # eval-mode forward of the updated model: finite, right shape
+    assert est.shape == (B, c["F"], c["T"]) and bool(torch.isfinite(est).all())
+    loss_ref, est_ref, grads_ref = oracle.loss_and_grads(sb.meg, sb.positions(), sb.subject_index,
+                                                         sb.features, True, ban)
+    assert abs(float(loss) - float(loss_ref)) < LOSS_TOL, (float(loss), float(loss_ref))
+    gscale = max(v.double().norm().item() for v in grads_ref.values())
+    worst = (0.0, "")
+    for k, p in model.named_parameters():
+        tol = GRAD_TOL if p.dim() > 1 else 3 * GRAD_TOL
+        assert close(p.grad, grads_ref[k], tol, gscale), (k, rel_l2(p.grad, grads_ref[k]))
+        if not is_noise_grad(grads_ref[k], gscale):
+            worst = max(worst, (rel_l2(p.grad, grads_ref[k]), k))
+    print(f"full-size {cfg_name} B={B}: loss {float(loss):.7f} vs oracle {float(loss_ref):.7f}, "
+          f"worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+
+
+def test_offset_meg_ms_slicing_like_the_reference():
+    """bm/solver.py:262-274 with conf/config.yaml task.offset_meg_ms=150 at 120 Hz: the MEG window drops
+    its first 18 samples, features and mask drop their last 18 (361 -> 343 samples)."""
+    from brainmagick_amd.solver import Solver
+    model, cfg = _small_model()
+    T, off = 361, int(150 / 1000 * 120)
+    assert off == 18
+    sb = synthetic.make_batch(4, 20, T, 10, 3, seed=21)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, 32, 10)
+    ban = torch.tensor([0.2, 0.3])
+    model.merger.ban_center_override = ban
+    solver = Solver(model, offset_meg_ms=150., sample_rate=120.)
+    estimate, output, features_mask, reject_mask = solver._process_batch(sb, training=True)
+    assert estimate.shape == (4, 10, T - off) and output.shape == (4, 10, T - off)
+    assert features_mask.shape == (4, 1, T - off) and bool(reject_mask.all())
+    assert torch.equal(output.cpu(), sb.features[..., :-off])
+    loss = solver.train_step(sb)
+    loss_ref, est_ref, grads_ref = oracle.loss_and_grads(
+        sb.meg[..., off:].contiguous(), sb.positions(), sb.subject_index,
+        sb.features[..., :-off].contiguous(), True, ban)
+    assert rel_l2(estimate, est_ref) < FWD_TOL
+    assert abs(float(loss) - float(loss_ref)) < LOSS_TOL
+    gscale = max(v.double().norm().item() for v in grads_ref.values())
+    for k, p in model.named_parameters():
+        assert close(p.grad, grads_ref[k], GRAD_TOL, gscale), (k, rel_l2(p.grad, grads_ref[k]))
+
+
+def test_out_of_range_subject_index_raises_like_the_reference_gather():
+    """bm/models/common.py:57 gathers `weights[subjects]`: an index outside the table raises.  Here the
+    device-side check clamps (no out-of-bounds read) and flags; the error surfaces at the Solver's
+    next synchronisation point (or immediately under BM_CHECK_INDICES=1)."""
+    from brainmagick_amd import hip_ops as H
+    from brainmagick_amd.solver import Solver
+    model, cfg = _small_model()
+    sb = synthetic.make_batch(4, 20, 32, 10, 3, seed=5)
+    solver = Solver(model)
+    solver.train_step(sb)
+    H.raise_if_index_error("cuda")                     # clean
+    bad = sb.replace(subject_index=torch.tensor([0, 1, 7, 2]))
+    solver.train_step(bad)                             # 7 >= 3 subjects: flagged, not read out of bounds
+    with pytest.raises(IndexError):
+        solver.train_step(sb)                          # reported at the next step's sync point
+    solver.train_step(sb)                              # flag was cleared
+
+
+def test_node_negatives_refuse_per_rank_rejection():
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
+    model, cfg = _small_model()
+    scaler = DeviceBatchScaler(torch.zeros(2, 20), torch.ones(2, 20))
+    with pytest.raises(ValueError):
+        Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=False))
+    Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=True))
+
+
+def test_flat_adam_is_a_torch_optimizer_and_checkpoints_round_trip():
+    """bm/solver.py:64,115-117 put optimizer.state_dict() into the checkpoint and load it back."""
+    from brainmagick_amd.optim import FlatAdam
+    from brainmagick_amd.solver import Solver
+    model, cfg = _small_model()
+    sb = synthetic.make_batch(4, 20, 32, 10, 3, seed=5)
+    solver = Solver(model)
+    assert isinstance(solver.optimizer, torch.optim.Optimizer)
+    for _ in range(3):
+        solver.train_step(sb)
+    sd = copy.deepcopy(solver.optimizer.state_dict())
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["lr"] == 3e-4
+    assert float(sd["state"][0]["step"]) == 3.0
+    # a torch.optim.Adam over the same parameters accepts the checkpoint (interchangeable layout)
+    ref_opt = torch.optim.Adam([p.detach().clone().requires_grad_() for p in model.parameters()], lr=3e-4)
+    ref_opt.load_state_dict(sd)
+    # resume: a second solver loaded from the checkpoint continues bit-identically
+    model2, _ = _small_model()
+    model2.load_state_dict(copy.deepcopy(model.state_dict()))
+    solver2 = Solver(model2)
+    solver2.optimizer.load_state_dict(sd)
+    la, lb = solver.train_step(sb), solver2.train_step(sb)
+    assert torch.equal(la, lb)
+    assert torch.equal(solver.optimizer.flat_param, solver2.optimizer.flat_param)
+    # lr schedulers reach the kernel through param_groups
+    solver.optimizer.param_groups[0]["lr"] = 0.0
+    before = solver.optimizer.flat_param.clone()
+    solver.train_step(sb)
+    assert torch.equal(before, solver.optimizer.flat_param)
+
+
 def test_full_batch_properties():
     """BASELINE cfg2 at its full size (B=256): size-independent properties of the hot path --
     run-to-run bit determinism, finite loss, probabilities rows sum to 1, the diagonal target,
@@ -279,6 +398,7 @@ def test_eval_mode_single_kernel_layers_match_train_stats_path():
 NCCL_WORKER = r'''
 import os, sys, copy, torch
 sys.path.insert(0, sys.argv[1])
+backend = sys.argv[2]
 from brainmagick_amd import distrib, synthetic
 from brainmagick_amd.models import SimpleConv
 from brainmagick_amd.solver import Solver
@@ -291,46 +411,107 @@ def run(negatives):
     solver = Solver(model, negatives=negatives)
     sb = synthetic.make_batch(8, 30, 64, 12, 4, seed=3)
     losses = [float(solver.train_step(sb)) for _ in range(3)]
-    return losses, solver.optimizer.flat_param.clone()
-plain_losses, plain_params = run("local")          # before init: world_size 1, no collectives
+    sd = solver.optimizer.state_dict()          # gathers the sharded moments
+    return losses, solver.optimizer.flat_param.clone(), sd["state"][0]["exp_avg"].clone(), \
+        model.state_dict()["encoders.meg.sequence.0.1.running_var"].clone()
+plain = run("local")          # before init: world_size 1, no collectives
 os.environ["BM_FORCE_DISTRIBUTED"] = "1"
-distrib.init("nccl")
+distrib.init(backend)
 assert distrib.is_distributed() and distrib.world_size() == 1
-rccl_losses, rccl_params = run("node")             # reduce_scatter / all_gather / candidate gather on RCCL
-assert plain_losses == rccl_losses, (plain_losses, rccl_losses)
-assert torch.equal(plain_params, rccl_params)
+assert distrib.comm_kind() == {"rccl": "rccl/c-abi", "nccl": "torch.distributed/nccl"}[backend]
+coll = run("node")            # reduce-scatter / all-gather / candidate gather / buffer all-reduce on RCCL
+assert plain[0] == coll[0], (plain[0], coll[0])
+for a, b in zip(plain[1:], coll[1:]):
+    assert torch.equal(a, b)
 m = distrib.average_metrics({"loss": 2.0}, 3)
 assert abs(m["loss"] - 2.0) < 1e-6
+assert distrib.max_over_ranks(1.5) == 1.5
 distrib.sync_buffers(torch.nn.BatchNorm1d(4).cuda())
-torch.distributed.destroy_process_group()
+distrib.barrier()
+distrib.shutdown()
 print("NCCL_WORKER_OK")
 '''
 
 
-def test_rccl_code_path_world1(tmp_path):
-    """The real RCCL collectives (reduce_scatter_tensor / all_gather_into_tensor on the flat bucket,
-    candidate all-gather on the side stream) at world_size 1 must reproduce the plain step bit for
-    bit.  (Multi-rank semantics are covered by the 2-process gloo test on CPU.)"""
+@pytest.mark.parametrize("backend", ["rccl", "nccl"])
+def test_rccl_code_path_world1(tmp_path, backend):
+    """The real RCCL collectives -- behind the C-ABI (bm_comm_*: in-place reduce-scatter / all-gather on
+    the flat bucket, candidate all-gather on the side stream, buffer all-reduce) and through the
+    torch.distributed fallback -- at world_size 1 must reproduce the plain step bit for bit.  (Multi-rank
+    semantics are covered by the 2-process gloo test on CPU and by the 2-GPU test below.)"""
     import os
     import subprocess
     import sys
     from pathlib import Path
     script = tmp_path / "nccl_worker.py"
     script.write_text(NCCL_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="1", RANK="0",
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("BM_FORCE_DISTRIBUTED", None)
     root = Path(__file__).resolve().parent.parent
-    out = subprocess.run([sys.executable, str(script), str(root)], env=env, capture_output=True,
+    out = subprocess.run([sys.executable, str(script), str(root), backend], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "NCCL_WORKER_OK" in out.stdout, out.stdout + out.stderr
 
 
+TWO_RANK_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from brainmagick_amd import distrib, synthetic
+from brainmagick_amd.models import SimpleConv
+from brainmagick_amd.solver import Solver
+distrib.init()
+r, w = distrib.rank(), distrib.world_size()
+assert w == 2 and distrib.comm_kind() == "rccl/c-abi"
+cfg = dict(depth=4, kernel_size=3, dilation_period=5, batch_norm=True, skip=True, gelu=True, glu=2,
+           glu_context=1, complex_out=True, merger=True, merger_pos_dim=128, merger_channels=24,
+           merger_dropout=0.0, initial_linear=24, subject_layers=True, subject_dim=0)
+torch.manual_seed(0)
+model = SimpleConv(in_channels={"meg": 30}, out_channels=12, hidden={"meg": 32}, n_subjects=4, **cfg)
+solver = Solver(model, device=f"cuda:{r}", negatives="node")
+sb = synthetic.make_batch(8, 30, 64, 12, 4, seed=3 + r)
+losses = [float(solver.train_step(sb)) for _ in range(3)]
+# replicas stay identical: parameters and BatchNorm buffers
+flat = torch.cat([solver.optimizer.flat_param, solver._buffers.flat])
+lo = flat.clone(); hi = flat.clone()
+distrib.comm().all_reduce(hi, "max"); neg = -lo; distrib.comm().all_reduce(neg, "max")
+assert torch.equal(hi, -neg), "replicas diverged"
+assert all(l == l for l in losses)
+distrib.barrier(); distrib.shutdown()
+print("TWO_RANK_OK", r, losses)
+'''
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_visible(tmp_path):
+    """2 processes x 1 GPU over the C-ABI RCCL communicator (skipped on the 1-GPU test box)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs")
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(TWO_RANK_WORKER)
+    root = Path(__file__).resolve().parent.parent
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2", RANK=str(r),
+                   LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("BM_FORCE_DISTRIBUTED", None)
+        procs.append(subprocess.Popen([sys.executable, str(script), str(root)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"TWO_RANK_OK {r}" in out, out
+
+
 def test_training_curve_and_top10_parity():
-    """SURVEY.md §8d accuracy parity, scaled to what the CPU oracle does in seconds: train the same
-    initial state on the same learnable (planted-latent) batches with the HIP path and with the
-    oracle; the loss curves must agree within 1 % (relative, every step) and the top-10 / top-1
-    segment-retrieval accuracy on 256 held-out segments within +-1 point of each other."""
+    """SURVEY.md §8d accuracy parity: train the same initial state for 200 steps on the same learnable
+    (planted-latent) batches with the HIP path and with the oracle; the loss curves must agree within
+    1 % (relative, every step) and the top-10 / top-1 segment-retrieval accuracy on 2 048 held-out
+    segments within +-1 point of each other.  The planted noise (0.8) keeps the task far from
+    saturation -- the oracle lands at ~52 % top-10 / ~20 % top-1 (chance 0.5 %) -- so that a precision
+    regression of the HIP path would move the number."""
     from brainmagick_amd.models import SimpleConv
     from brainmagick_amd.solver import Solver
     from brainmagick_amd.losses import ClipLoss
@@ -338,13 +519,14 @@ def test_training_curve_and_top10_parity():
     cfg = dict(O.CLIP_CONV_CFG)
     cfg.update(merger_pos_dim=128, merger_channels=32, initial_linear=32, depth=6,
                merger_dropout=0.0)
-    C, T, Fd, S, B, hidden, steps = 24, 96, 16, 4, 32, 48, 60
+    C, T, Fd, S, B, hidden, steps, n_batches, n_held, noise = 24, 96, 16, 4, 32, 48, 200, 32, 2048, 0.8
     torch.manual_seed(5)
     model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden},
                        n_subjects=S, **cfg)
     oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, hidden, Fd)
     solver = Solver(model)
-    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True) for i in range(8)]
+    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True, noise=noise)
+               for i in range(n_batches)]
     hip_losses, ref_losses = [], []
     for step in range(steps):
         sb = batches[step % len(batches)]
@@ -352,18 +534,18 @@ def test_training_curve_and_top10_parity():
         ref_losses.append(float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index,
                                                   sb.features)[0]))
     hip, ref = torch.tensor(hip_losses), torch.tensor(ref_losses)
-    assert ref[-8:].mean() < 0.8 * ref[:8].mean(), "planted task should be learnable"
+    assert ref[-8:].mean() < 0.5 * ref[:8].mean(), "planted task should be learnable"
     assert ((hip - ref).abs() / ref.abs()).max().item() < 1e-2, (hip_losses[-5:], ref_losses[-5:])
-    held = synthetic.make_batch(256, C, T, Fd, S, seed=999, planted=True)
+    held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
     est_hip, cand = solver.predict(held)
     est_ref = oracle.forward(held.meg, held.positions(), held.subject_index)
     acc_hip = retrieval.segment_topk_accuracy(ClipLoss().cuda(), est_hip, cand, topks=(1, 10))
     probs_ref = O.clip_probabilities(est_ref, held.features)
-    labels = torch.arange(256)
+    labels = torch.arange(n_held)
+    acc_ref = {k: O.topk_accuracy(probs_ref, labels, labels, k) for k in (1, 10)}
+    assert 0.40 <= acc_ref[10] <= 0.70, ("the planted task must stay away from saturation", acc_ref)
     for k in (1, 10):
-        acc_ref = O.topk_accuracy(probs_ref, labels, labels, k)
-        assert abs(acc_hip[f"top{k}"] - acc_ref) <= 0.01 + 1e-9, (k, acc_hip, acc_ref)
-    assert acc_hip["top10"] > 5 * 10 / 256, "must beat chance (10/256) by a wide margin"
+        assert abs(acc_hip[f"top{k}"] - acc_ref[k]) <= 0.01 + 1e-9, (k, acc_hip, acc_ref)
 
 
 def test_deep_mel_feature_model_step():
