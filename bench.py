@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--no-exact", action="store_true",
                     help="skip the extra timing blocks of the other fp32-class modes (profiling runs)")
     ap.add_argument("--no-clip", action="store_true", help="skip the ClipLoss contraction roofline block")
-    ap.add_argument("--dtype", default=hip_ops.DEFAULT_COMPUTE_DTYPE, choices=sorted(MODE_PEAK_TFLOPS),
+    ap.add_argument("--dtype", default=hip_ops.DEFAULT_COMPUTE_DTYPE, choices=sorted(hip_ops.COMPUTE_DTYPES),
                     help="compute mode of the contractions; every fp32-class mode (f16x2, f32x3, f32) is held to the "
                          "same parity tolerances; bf16 is opt-in REDUCED precision, for information only")
     args = ap.parse_args()
@@ -366,7 +366,7 @@ def main():
     other_modes = {}
     if not args.no_exact and args.dtype in ("f16x2", "f32x3"):
         for mode in ("f16x2", "f32x3", "f32"):
-            if mode == args.dtype:
+            if mode == args.dtype or mode not in hip_ops.COMPUTE_DTYPES:
                 continue
             hip_ops.set_compute_dtype(mode)
             k2 = max(2, args.steps // 4)

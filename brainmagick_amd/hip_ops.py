@@ -23,15 +23,16 @@ BKC = 16
 #   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
 DEFAULT_COMPUTE_DTYPE = "f32x3"
+COMPUTE_DTYPES = ("f32", "f32x3", "bf16")
 _compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE)
-if _compute_dtype not in ("f32", "f32x3", "bf16"):
-    raise ValueError(f"BM_COMPUTE_DTYPE must be f32, f32x3 or bf16, got {_compute_dtype!r}")
+if _compute_dtype not in COMPUTE_DTYPES:
+    raise ValueError(f"BM_COMPUTE_DTYPE must be one of {COMPUTE_DTYPES}, got {_compute_dtype!r}")
 
 
 def set_compute_dtype(name: str):
     global _compute_dtype
-    if name not in ("f32", "bf16", "f32x3"):
-        raise ValueError(f"compute dtype must be 'f32', 'f32x3' or 'bf16', got {name!r}")
+    if name not in COMPUTE_DTYPES:
+        raise ValueError(f"compute dtype must be one of {COMPUTE_DTYPES}, got {name!r}")
     _compute_dtype = name
 
 
