@@ -1,0 +1,569 @@
+// fp32-ACCURATE implicit-GEMM conv on the f16 matrix cores, compute mode "f16x2".
+//
+// Every fp32 operand x is scaled by a power of two s (so that the largest magnitude of its tensor -- or, for
+// the weights, of its output row -- lands in [2^14, 2^15)) and split into TWO f16 numbers
+//     x * s = hi + lo + e,   hi = f16(x s),  lo = f16(x s - hi),   |e| <= 2^-22 |x s|
+// (11 + 11 significand bits, round to nearest twice).  A product a * b is evaluated as the three partial
+// products  a.lo * b.hi + a.hi * b.lo + a.hi * b.hi  (the dropped a.lo * b.lo is <= 2^-22 |a b|), each an
+// EXACT f16 x f16 product accumulated in fp32 by v_mfma_f32_32x32x16_f16; the accumulator is multiplied by
+// the (exact) inverse scales in the epilogue.  Three 16-bit MFMAs per fp32-accurate 32x32x16 block instead of
+// the six of the 3 x bf16 split (conv_nn_x3w.hip): half the matrix-core time for the same parity tolerances --
+// measured rel-L2 against fp64 is that of an fp32 FMA chain (tests/test_exact_f32_gpu.py), because the fp32
+// accumulation error dominates both.  The error bound is norm-wise (relative to the largest element of the
+// tensor / weight row), not element-wise: an element 2^-18 below its tensor's maximum keeps fewer than 22
+// bits; the reference's activations (BatchNorm'ed / clamped, bm/norm.py:332-333) span a few binades.
+//
+// Structure = conv_nn_x3w.hip (ONE workgroup of four wavefronts per CU, one wavefront per SIMD, wavefront
+// tile (32 MW) x 96 as MW x 3 MFMA accumulators, workgroup tile (64 MW) x 192, MW in {5, 4, 2}; weight slab
+// of stage s + 2 by LDS DMA, input window of the next chunk through registers, raw s_barrier with hand-counted
+// vmcnt), with two operand planes: stage = (16-channel chunk, tap) = 15 MW MFMAs per wavefront.
+// LDS: A [3 buffers][2 planes][2 groups][64 MW rows], X [2 buffers][2 planes][2 groups][256 columns] x 16 B.
+// Packed weights: [g][chunk32][tap][plane][4 groups][Mpad] 16-byte slots (8 f16 channels), followed by the
+// per-row inverse scales [G][Mpad] fp32 (bm_pack_weights_h2).
+#include <cstdlib>
+#include <cstring>
+#include "conv_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4h __attribute__((ext_vector_type(4)));
+
+#define HBN 192           // columns of the workgroup tile (2 wavefront columns x 3 blocks)
+#define HXWP 256          // padded x-window width (>= 192 + 2 * 16; one column per thread)
+#define HXSLAB (2 * 2 * HXWP)     // 16-byte slots of one X buffer
+
+struct ConvH2Args {
+    ConvNNArgs c;
+    const float* x_amax;      // [1] largest |x| of the input tensor (upper bounds are fine), device memory
+    const float* wscale;      // [G][Mpad] inverse row scales written by bm_pack_weights_h2
+};
+
+// Power-of-two scale s with amax * s in [2^14, 2^15), and its exact inverse.  amax == 0 / subnormal / inf /
+// nan: s = 1 (non-finite operands then propagate through the split as inf / nan like in fp32).
+__host__ __device__ __forceinline__ void h2_scale_from_amax(float amax, float& s, float& inv) {
+    unsigned bits;
+    memcpy(&bits, &amax, 4);
+    const unsigned e = (bits >> 23) & 0xffu;
+    int se = 127;
+    if (e != 0u && e != 255u) {
+        se = 268 - (int)e;              // 127 + 14 - (e - 127)
+        se = se > 253 ? 253 : (se < 1 ? 1 : se);
+    }
+    const unsigned sb = (unsigned)se << 23, ib = (unsigned)(254 - se) << 23;
+    memcpy(&s, &sb, 4);
+    memcpy(&inv, &ib, 4);
+}
+
+// 8 fp32 values (already scaled) -> f16 planes hi, lo
+__device__ __forceinline__ void split8h(const float* f, float s, u32x4& hi, u32x4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float xs = f[i] * s;
+        const _Float16 a = (_Float16)xs;
+        h[i] = a;
+        l[i] = (_Float16)(xs - (float)a);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ float ch_ld32(i32x4h rs, int voff) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
+
+// Epilogue helpers: every accumulator block is addressed with compile-time indices (template recursion), so
+// the MW x 3 accumulators never leave the register file.
+template <int MW>
+struct H2Simple {
+    float* yb;
+    const float* rb;
+    int rowu, li, T;
+    float bia[MW][16];
+};
+
+template <int MW, int NT, int MT>
+__device__ __forceinline__ void h2_simple_col(const H2Simple<MW>& e, f32x16 (&acc)[MW][3]) {
+    if constexpr (MT < MW) {
+        float rv[16];
+        if (e.rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rv[r] = e.rb[(long)(e.rowu + MT * 32 + (r & 3) + 8 * (r >> 2)) * e.T + e.li + NT * 32];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[MT][NT][r] + e.bia[MT][r];
+            if (e.rb) v += rv[r];
+            e.yb[(long)(e.rowu + MT * 32 + (r & 3) + 8 * (r >> 2)) * e.T + e.li + NT * 32] = v;
+        }
+        h2_simple_col<MW, NT, MT + 1>(e, acc);
+    }
+}
+
+template <int MW, int I>
+__device__ __forceinline__ void h2_general_blocks(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* ep, int b,
+                                                  int m0, int rl_base, int col_base) {
+    if constexpr (I < MW * 3) {
+        constexpr int MT = I / 3, NT = I % 3;
+        float v[16];
+        conv_ep_store_block(a, acc[MT][NT], ep, 64 * MW, b, m0, rl_base + MT * 32, col_base + NT * 32, v);
+        h2_general_blocks<MW, I + 1>(a, acc, ep, b, m0, rl_base, col_base);
+    }
+}
+
+template <int N, int MW>
+__device__ __forceinline__ void h2_barrier(f16x8 (&ah)[MW], f16x8 (&bh)[3]) {
+    if constexpr (MW == 5)
+        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(ah[4]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
+                     : "n"(N) : "memory");
+    else if constexpr (MW == 4)
+        asm volatile("s_waitcnt vmcnt(%7) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
+                     : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
+                     : "n"(N) : "memory");
+}
+
+template <int KS, int MW>
+__global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
+    const ConvNNArgs& a = args.c;
+    constexpr int NW = 3;
+    constexpr int HBM = 64 * MW;                      // rows of the workgroup tile
+    constexpr int HASLAB = 2 * 2 * HBM;               // 16-byte slots of one A buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* As = reinterpret_cast<u32x4*>(smem);       // [3 buffers][2 planes][2 groups][HBM]
+    u32x4* Xs = As + 3 * HASLAB;                      // [2 buffers][2 planes][2 groups][HXWP]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nl = lane & 31;
+    const int h = lane >> 5;
+
+    int id = bm_xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = id % a.ntiles_m;
+    id /= a.ntiles_m;
+    const int ntile = id % a.ntiles_n;
+    const int b = id / a.ntiles_n;
+    const int m0 = mtile * HBM;
+    const int n0 = ntile * HBN;
+    const int halo = (KS >> 1) * a.dil;
+    const int XW = HBN + 2 * halo;                    // <= 224
+
+    const int g = a.widx ? a.widx[b] : 0;
+    const int nchunk32 = a.nchunk;
+    const int n16 = (a.Cin + 15) >> 4;                // channels past Cin read 0 through the bounds check
+    const int nstage = n16 * KS;
+    // packed weights in 16-byte slots: [g][chunk32][tap][plane][4][Mpad]
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (long)g * nchunk32 * KS * 8 * a.Mpad + m0 + lane;
+    float sx, sx_inv;
+    h2_scale_from_amax(*args.x_amax, sx, sx_inv);
+
+    // input window of this segment through a bounds-checked buffer descriptor: channels past Cin read 0
+    const unsigned long long xaddr = (unsigned long long)(a.x + (long)b * a.x_bstride);
+    i32x4h xr;
+    xr[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xaddr);
+    xr[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xaddr >> 32) & 0xffffu));
+    xr[2] = __builtin_amdgcn_readfirstlane(a.Cin * a.T * 4);
+    xr[3] = 0x00020000;
+    // thread `tid` stages window column tid (both 8-channel groups); columns outside [0, T) or past the
+    // window get an offset that stays out of range for every channel -> they read as 0 (conv zero padding)
+    const int tcol = n0 - halo + tid;
+    const int xoff0 = (tid < XW && tcol >= 0 && tcol < a.T) ? tcol * 4 : 0x40000000;
+    const int crow = a.T * 4;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    float xreg[16];
+    f16x8 af[2][MW], bf[2][NW];                       // operand fragments [plane 0 = hi, 1 = lo]
+
+    // DMA of the A slab of stage S_ (clamped to the last stage) into A buffer BUF3_: 4 MW pieces of 64 slots,
+    // MW per wavefront
+#define DMA_A(S_, BUF3_)                                                                          \
+    {                                                                                             \
+        const int sc = (S_) < nstage ? (S_) : nstage - 1;                                         \
+        const int c16 = sc / KS, jj = sc - c16 * KS;                                              \
+        const u32x4* src = wg + ((long)((c16 >> 1) * KS + jj) * 8 + (c16 & 1) * 2) * a.Mpad;      \
+        _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                          \
+            const int k = wave + 4 * i;                                                           \
+            const int run = k / MW, rb = k - run * MW;          /* run = plane * 2 + group */     \
+            const int plane = run >> 1, kg = run & 1;                                             \
+            __builtin_amdgcn_global_load_lds(                                                     \
+                (const void*)(src + (long)(plane * 4 + kg) * a.Mpad + rb * 64),                   \
+                (__attribute__((address_space(3))) void*)(As + (BUF3_) * HASLAB + run * HBM + rb * 64), 16, 0, 0); \
+        }                                                                                         \
+    }
+    // 16 channels x 1 column of the input window of chunk C16_ (zeros past the last chunk: offset out of range)
+#define LOAD_X(C16_)                                                                              \
+    {                                                                                             \
+        const int cb = (C16_) * 16 * crow + xoff0;                                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) xreg[r] = ch_ld32(xr, cb + r * crow);      \
+    }
+#define CH_WAIT_X(N_)                                                                             \
+    asm volatile("s_waitcnt vmcnt(%16)"                                                           \
+                 : "+v"(xreg[0]), "+v"(xreg[1]), "+v"(xreg[2]), "+v"(xreg[3]), "+v"(xreg[4]), "+v"(xreg[5]),  \
+                   "+v"(xreg[6]), "+v"(xreg[7]), "+v"(xreg[8]), "+v"(xreg[9]), "+v"(xreg[10]), "+v"(xreg[11]), \
+                   "+v"(xreg[12]), "+v"(xreg[13]), "+v"(xreg[14]), "+v"(xreg[15])                 \
+                 : "n"(N_) : "memory");
+#define STORE_X(BUF_)                                                                             \
+    {                                                                                             \
+        u32x4* xd = Xs + (BUF_) * HXSLAB + tid;                                                   \
+        _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                        \
+            u32x4 hi, lo;                                                                         \
+            split8h(xreg + 8 * kg, sx, hi, lo);                                                   \
+            xd[(0 * 2 + kg) * HXWP] = hi;                                                         \
+            xd[(1 * 2 + kg) * HXWP] = lo;                                                         \
+        }                                                                                         \
+    }
+    // fragments a stage needs first (A.lo, B.hi); ABUF_ = its A buffer, XB_/J_ = its X buffer and tap
+#define FRAGS_EARLY(ABUF_, XB_, J_)                                                               \
+    {                                                                                             \
+        const u32x4* ab = As + (ABUF_) * HASLAB + h * HBM + wm * (MW * 32) + nl;                  \
+        const u32x4* xb = Xs + (XB_) * HXSLAB + h * HXWP + wn * (NW * 32) + nl + (J_) * a.dil;    \
+        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[0][nt] = __builtin_bit_cast(f16x8, xb[0 * 2 * HXWP + nt * 32]); \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(f16x8, ab[1 * 2 * HBM + mt * 32]); \
+    }
+#define FRAGS_LATE(ABUF_, XB_, J_)                                                                \
+    {                                                                                             \
+        const u32x4* ab = As + (ABUF_) * HASLAB + h * HBM + wm * (MW * 32) + nl;                  \
+        const u32x4* xb = Xs + (XB_) * HXSLAB + h * HXWP + wn * (NW * 32) + nl + (J_) * a.dil;    \
+        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(f16x8, ab[0 * 2 * HBM + mt * 32]); \
+        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[1][nt] = __builtin_bit_cast(f16x8, xb[1 * 2 * HXWP + nt * 32]); \
+    }
+#define TERM(PA_, PB_)                                                                            \
+    _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
+        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt)                                         \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA_][mt], bf[PB_][nt], acc[mt][nt], 0, 0, 0);
+    // "slab s + 1 landed" + workgroup barrier: N_ younger VMEM instructions may stay in flight.  The statement
+    // names the A.hi and B.hi fragments as read-write operands: the compiler moves register-only MFMAs freely
+    // across an asm statement ("memory" does not order them), and this pins lo*hi / hi*hi (readers of B.hi)
+    // before the barrier and hi*lo (reader of A.hi) after it, where it covers the LDS latency of the next
+    // stage's early fragments.
+#define CH_BARRIER(N_) h2_barrier<N_, MW>(af[0], bf[0]);
+
+    // prologue: slabs 0 and 1, input window of chunk 0
+    DMA_A(0, 0)
+    DMA_A(1, 1)
+    LOAD_X(0)
+    CH_WAIT_X(0)
+    STORE_X(0)
+    if (KS == 1) LOAD_X(1)          // 1x1 convs: the window of chunk c + 2 is requested in stage c (see below)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FRAGS_EARLY(0, 0, 0)
+
+    // Stage s = (16-channel chunk c16, tap j), A buffer s % 3, X buffer c16 & 1.  VMEM queue order inside a
+    // stage: [input window of chunk c16 + 1, 16 loads, if j == 0], slab s + 2 (MW DMA copies).  Before the
+    // barrier slab s + 1 must have landed: younger than it are MW (+ 16 if j == 0) instructions.  The input
+    // window is consumed in the stage with j == KS - 1: younger than it are the KS slabs issued since.
+    // KS == 1 (every stage is a window stage): the window of chunk c + 1 was requested in stage c - 1 after its
+    // slab; it is split in stage c, and only then is the window of chunk c + 2 requested into the same
+    // registers - queue order per stage: slab s + 2 (MW), window s + 2 (16); younger than slab s + 1 at the
+    // barrier: window s + 1, slab s + 2, window s + 2 = 32 + MW.
+    // MFMA order of a stage: lo*hi and hi*hi before the barrier, hi*lo after it; the early fragments of the
+    // next stage (A.lo, B.hi) are read under that last term, which does not use them.
+    int s = 0;
+    int ab3 = 0;                                      // s % 3
+    for (int c16 = 0; c16 < n16; ++c16) {
+        const int xbuf = c16 & 1;
+#pragma unroll
+        for (int j = 0; j < KS; ++j, ++s) {
+            const int ab_next = ab3 == 2 ? 0 : ab3 + 1;
+            const int ab_next2 = ab_next == 2 ? 0 : ab_next + 1;
+            if (KS != 1 && j == 0) LOAD_X(c16 + 1)
+            DMA_A(s + 2, ab_next2)
+            FRAGS_LATE(ab3, xbuf, j)
+            if (j == KS - 1) {
+                if (KS == 1) CH_WAIT_X(MW) else CH_WAIT_X(KS * MW)
+                STORE_X(xbuf ^ 1)
+                if (KS == 1) LOAD_X(c16 + 2)
+            }
+            TERM(1, 0) TERM(0, 0)
+            if (j == KS - 1) {       // spread the split arithmetic of the input window between the MFMAs
+                _Pragma("unroll") for (int g_ = 0; g_ < 6 * MW; ++g_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+            }
+            if (KS == 1) CH_BARRIER(32 + MW) else if (j == 0) CH_BARRIER(16 + MW) else CH_BARRIER(MW)
+            if (j == KS - 1) FRAGS_EARLY(ab_next, xbuf ^ 1, 0) else FRAGS_EARLY(ab_next, xbuf, j + 1)
+            TERM(0, 1)
+            ab3 = ab_next;
+        }
+    }
+    // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#undef DMA_A
+#undef LOAD_X
+#undef CH_WAIT_X
+#undef STORE_X
+#undef FRAGS_EARLY
+#undef FRAGS_LATE
+#undef TERM
+#undef CH_BARRIER
+
+    // epilogue: inverse scales (exact powers of two), bias, optional pre-activation store, per-channel affine,
+    // activation, residual.  One literal-indexed expansion per accumulator block keeps the accumulators in
+    // registers.  ep[3 HBM .. 4 HBM) = per-row accumulator factor = inverse weight-row scale x inverse x scale.
+    float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
+    conv_ep_stage_params(a, ep, HBM, m0, tid, 256);
+    {
+        const float* ws = args.wscale + (long)g * a.Mpad + m0;
+        for (int i = tid; i < HBM; i += 256) ep[3 * HBM + i] = ws[i] * sx_inv;
+    }
+    __syncthreads();
+    {
+        const float* fl = ep + 3 * HBM + wm * (MW * 32) + 4 * h;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = fl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                for (int nt = 0; nt < NW; ++nt) acc[mt][nt][r] *= f;
+            }
+    }
+    // Common case (every wide launch of the training step): one output tensor, no affine / activation, tile
+    // fully inside M.  Row addresses are wave-uniform bases + one per-lane offset + an immediate per column
+    // block, the row biases are read once: ~3 VALU issue slots per stored element instead of ~10.
+    const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE &&
+                        m0 + HBM <= a.M;
+    if (simple) {
+        H2Simple<MW> e;
+        e.yb = (a.y_pre ? a.y_pre : a.y_out) + (long)b * a.y_bstride;
+        e.rb = (a.y_out && a.res) ? a.res + (long)b * a.res_bstride : nullptr;
+        e.rowu = m0 + wm * (MW * 32);                       // wave-uniform first row
+        e.li = 4 * h * a.T + n0 + wn * (NW * 32) + nl;      // per-lane element offset inside a row block
+        e.T = a.T;
+        const float* epl = ep + wm * (MW * 32) + 4 * h;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e.bia[mt][r] = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+        const int col0 = n0 + wn * (NW * 32) + nl;
+        if (col0 < a.T) h2_simple_col<MW, 0, 0>(e, acc);
+        if (col0 + 32 < a.T) h2_simple_col<MW, 1, 0>(e, acc);
+        if (col0 + 64 < a.T) h2_simple_col<MW, 2, 0>(e, acc);
+    } else {
+        h2_general_blocks<MW, 0>(a, acc, ep, b, m0, wm * (MW * 32) + 4 * h, n0 + wn * (NW * 32) + nl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static int h2_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("BM_H2_WIDE");      // BM_H2_WIDE=0: everything through the 3 x bf16 kernels
+        on = !(e && e[0] == '0');
+    }
+    return on;
+}
+
+// rows per wavefront-row block: the workgroup tile is 64 MW rows; MW in {5, 4, 2} minimising the padded rows
+// (ties -> the larger tile)
+extern "C" int bm_conv_h2_mw_for(int M) {
+    int best = 5;
+    long best_pad = -1;
+    const int cand[3] = {5, 4, 2};
+    for (int i = 0; i < 3; ++i) {
+        const long bm = 64L * cand[i];
+        const long pad = (long)cdiv(M, bm) * bm;
+        if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = cand[i]; }
+    }
+    return best;
+}
+extern "C" int bm_conv_h2_mpad(int M) {
+    const int bm = 64 * bm_conv_h2_mw_for(M);
+    return cdiv(M, bm) * bm;
+}
+
+// 1 when the wide f16x2 kernel covers this conv shape (otherwise the caller packs for / launches the 3 x bf16
+// kernels of conv_nn_x3.hip, which are fp32-accurate as well)
+extern "C" int bm_conv_h2_covers(int Cin, int M, int T, int KS, int dil) {
+    if (!h2_enabled() || (KS != 1 && KS != 3)) return 0;
+    if ((KS >> 1) * dil > 16 || T <= 128) return 0;
+    if ((long)Cin * T * 4 >= 0x40000000L) return 0;
+    // padded rows are wasted MFMA work: leave tiny layers (tests, F = 16 heads) to the narrow kernels
+    return (long)bm_conv_h2_mpad(M) * 2 <= (long)M * 3 || M >= 96;
+}
+
+// bytes of the packed buffer: f16 planes [G][chunk32][KS][2][4][Mpad][8] + fp32 inverse row scales [G][Mpad]
+extern "C" long bm_packed_weight_bytes_h2(int G, int M, int Cin, int KS) {
+    const long mpad = bm_conv_h2_mpad(M);
+    return (long)G * cdiv(Cin, 32) * KS * 2 * 4 * mpad * 8 * 2 + (long)G * mpad * 4;
+}
+
+// One workgroup per (group, padded row): row maximum -> power-of-two scale -> the row's 16-byte slots of both
+// planes (zeros for padded rows / channels) and its inverse scale.
+__global__ __launch_bounds__(128) void pack_weights_h2_kernel(const float* __restrict__ src,
+                                                              unsigned short* __restrict__ dst,
+                                                              float* __restrict__ wscale, int M, int Cin, int KS,
+                                                              long sg, long sm, long sc, long sj, int flip, int Mpad,
+                                                              int nchunk, const float* alpha_ptr) {
+    __shared__ float red[2];
+    const int m = blockIdx.x % Mpad, g = blockIdx.x / Mpad;
+    const float alpha = alpha_ptr ? *alpha_ptr : 1.f;
+    const int nk = Cin * KS;
+    float mx = 0.f;
+    if (m < M)
+        for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+            const int c = i / KS, j = i - c * KS;
+            mx = fmaxf(mx, fabsf(alpha * src[g * sg + m * sm + c * sc + j * sj]));
+        }
+    mx = bm_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    float s, inv;
+    h2_scale_from_amax(fmaxf(red[0], red[1]), s, inv);
+    if (threadIdx.x == 0) wscale[(long)g * Mpad + m] = inv;
+    // slot index inside this row: (chunk, tap, group) -> 8 channels
+    const int nslots = nchunk * KS * 4;
+    const long plane_stride = (long)4 * Mpad * 8;           // f16 elements of one plane of one (chunk, tap)
+    for (int q = threadIdx.x; q < nslots; q += blockDim.x) {
+        const int kg = q & 3;
+        const int j = (q >> 2) % KS;
+        const int chunk = (q >> 2) / KS;
+        alignas(16) unsigned short hi[8];
+        alignas(16) unsigned short lo[8];
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const int c = chunk * 32 + kg * 8 + e8;
+            float v = 0.f;
+            if (m < M && c < Cin) {
+                const int jj = flip ? KS - 1 - j : j;
+                v = alpha * src[g * sg + m * sm + c * sc + jj * sj] * s;
+            }
+            const _Float16 a = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)a);
+            hi[e8] = __builtin_bit_cast(unsigned short, a);
+            lo[e8] = __builtin_bit_cast(unsigned short, l);
+        }
+        const long stage = ((long)g * nchunk + chunk) * KS + j;
+        unsigned short* base = dst + stage * 2 * plane_stride + ((long)kg * Mpad + m) * 8;
+        *reinterpret_cast<uint4*>(base) = *reinterpret_cast<const uint4*>(hi);
+        *reinterpret_cast<uint4*>(base + plane_stride) = *reinterpret_cast<const uint4*>(lo);
+    }
+}
+
+extern "C" int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
+                                  long sc, long sj, int flip, const float* alpha_ptr, void* stream) {
+    BM_REQUIRE(src && dst, "pack_weights_h2: null pointer");
+    BM_REQUIRE(G > 0 && M > 0 && Cin > 0 && KS > 0, "pack_weights_h2: bad dims");
+    const int Mpad = bm_conv_h2_mpad(M);
+    const int nchunk = cdiv(Cin, 32);
+    const long f16_elems = (long)G * nchunk * KS * 2 * 4 * Mpad * 8;
+    float* wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + f16_elems * 2);
+    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3((unsigned)(G * Mpad)), dim3(128), 0, (hipStream_t)stream, src,
+                       (unsigned short*)dst, wscale, M, Cin, KS, sg, sm, sc, sj, flip, Mpad, nchunk, alpha_ptr);
+    return bm_check_launch("pack_weights_h2");
+}
+
+// out[0] = max |x[i]|  (bit pattern of a non-negative float orders like an unsigned integer; NaN sorts above
+// inf, so a non-finite input yields a non-finite maximum).  256 workgroups of 1024 threads, one atomic each.
+__global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    __shared__ unsigned red[16];
+    unsigned mx = 0u;
+    const long n4 = n >> 2;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const uint4 v = x4[i];
+        mx = max(max(mx, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) mx = max(mx, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        mx = red[threadIdx.x];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if (threadIdx.x == 0) atomicMax(out, mx);
+    }
+}
+
+extern "C" int bm_amax(const float* x, long n, float* out, void* stream) {
+    BM_REQUIRE(x && out && n >= 0, "amax: bad arguments");
+    BM_REQUIRE(((uintptr_t)x & 15) == 0, "amax: x must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, 4, s);
+    if (e != hipSuccess) return bm_set_error((int)e, "amax: hipMemsetAsync: %s", hipGetErrorString(e));
+    if (n == 0) return BM_OK;
+    long blocks = (n / 4 + 1023) / 1024;
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, x, n, reinterpret_cast<unsigned*>(out));
+    return bm_check_launch("amax");
+}
+
+template <int KS, int MW>
+static int launch_conv_nn_h2w(ConvH2Args args, hipStream_t stream) {
+    constexpr int HBM = 64 * MW;
+    size_t lds = (size_t)(3 * 2 * 2 * HBM + 2 * HXSLAB) * 16;
+    const size_t lds_ep = (size_t)4 * HBM * sizeof(float);
+    if (lds < lds_ep) lds = lds_ep;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_h2w_kernel<KS, MW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return bm_set_error((int)e, "conv_nn_h2w: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    args.c.ntiles_n = cdiv(args.c.T, HBN);
+    args.c.ntiles_m = args.c.Mpad / HBM;
+    const long nblocks = (long)args.c.B * args.c.ntiles_n * args.c.ntiles_m;
+    if (nblocks <= 0) return BM_OK;
+    hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
+    return bm_check_launch("conv_nn_h2w");
+}
+
+// Same contract as bm_conv1d_nn plus `x_amax` (device pointer to max |x|, e.g. from bm_amax; any upper bound
+// within a factor 2 of the fp16 range works); weights packed by bm_pack_weights_h2; only shapes for which
+// bm_conv_h2_covers() is 1.
+extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked,
+                               const int* widx, const float* bias, const float* ep_scale, const float* ep_shift,
+                               const float* res, long res_bstride, float* y_pre, float* y_out, long y_bstride,
+                               float* stats, int B, int Cin, int M, int T, int KS, int dil, int act, float leak,
+                               int G, void* stream) {
+    BM_REQUIRE(x && wpacked && x_amax, "conv1d_nn_h2: null x / w / x_amax");
+    BM_REQUIRE(y_pre || y_out, "conv1d_nn_h2: no output");
+    BM_REQUIRE(!stats, "conv1d_nn_h2: per-tile statistics are not produced by this kernel");
+    BM_REQUIRE(B >= 0 && Cin > 0 && M > 0 && T > 0 && dil >= 1 && G >= 1, "conv1d_nn_h2: bad dims");
+    BM_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv1d_nn_h2: scale/shift must come together");
+    BM_REQUIRE(bm_conv_h2_covers(Cin, M, T, KS, dil), "conv1d_nn_h2: shape not covered (Cin=%d M=%d T=%d KS=%d dil=%d)",
+               Cin, M, T, KS, dil);
+    ConvH2Args args;
+    ConvNNArgs& a = args.c;
+    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias;
+    a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
+    a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = nullptr;
+    a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;
+    const int mw = bm_conv_h2_mw_for(M);
+    a.Mpad = bm_conv_h2_mpad(M);
+    a.nchunk = cdiv(Cin, 32);
+    const long f16_elems = (long)G * a.nchunk * KS * 2 * 4 * a.Mpad * 8;
+    args.x_amax = x_amax;
+    args.wscale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpacked) + f16_elems * 2);
+    hipStream_t s = (hipStream_t)stream;
+#define H2_DISPATCH(MW_)                                                                 \
+    return KS == 1 ? launch_conv_nn_h2w<1, MW_>(args, s) : launch_conv_nn_h2w<3, MW_>(args, s);
+    switch (mw) {
+        case 5: H2_DISPATCH(5)
+        case 4: H2_DISPATCH(4)
+        default: H2_DISPATCH(2)
+    }
+#undef H2_DISPATCH
+}

@@ -47,10 +47,10 @@ class Conv1dFn(torch.autograd.Function):
         if transposed_weight:
             Cin, M, KS = weight.shape
             assert KS == 1, "ConvTranspose1d is only supported with kernel 1 (simpleconv.py:189)"
-            wp = H.pack_weights(weight, 1, M, Cin, 1, 0, 1, M, 0)
+            wp = H.pack_weights(weight, 1, M, Cin, 1, 0, 1, M, 0, shape=(x.shape[2], dil))
         else:
             M, Cin, KS = weight.shape
-            wp = H.pack_conv_fwd(weight)
+            wp = H.pack_conv_fwd(weight, (x.shape[2], dil))
         need_pre = act != H.ACT_NONE and (x.requires_grad or weight.requires_grad)
         pre, out, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, act=act, leak=leak, want_pre=need_pre)
         ctx.save_for_backward(x, weight, pre)
@@ -74,10 +74,10 @@ class Conv1dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if transposed_weight:
                 Cin, M, _ = weight.shape
-                wp = H.pack_weights(weight, 1, Cin, M, 1, 0, M, 1, 0)
+                wp = H.pack_weights(weight, 1, Cin, M, 1, 0, M, 1, 0, shape=(dy.shape[2], dil))
             else:
                 M, Cin, _ = weight.shape
-                wp = H.pack_conv_dgrad(weight)
+                wp = H.pack_conv_dgrad(weight, (dy.shape[2], dil))
             _, dx, _ = H.conv_nn(dy, wp, Cin, KS, dil)
         dw = _conv_weight_grads(dy, x, weight.shape, KS, dil, transposed_weight) \
             if ctx.needs_input_grad[1] else None
@@ -99,7 +99,7 @@ class ConvBNActFn(torch.autograd.Function):
         x, weight = _c(x), _c(weight)
         M, Cin, KS = weight.shape
         B, _, T = x.shape
-        wp = H.pack_conv_fwd(weight)
+        wp = H.pack_conv_fwd(weight, (T, dil))
         res = x if residual else None
         needs_grad = x.requires_grad or weight.requires_grad
         if training:
@@ -130,7 +130,7 @@ class ConvBNActFn(torch.autograd.Function):
                                                 leak, want_affine_grads=True, want_dbias=has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
-            _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight), Cin, KS, dil,
+            _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight, (dy.shape[2], dil)), Cin, KS, dil,
                                  res=dout if residual else None)
         dw = H.gemm_nt(dy, x, x.shape[0], M, Cin, x.shape[2], KS, dil).view(weight.shape) \
             if ctx.needs_input_grad[1] else None
@@ -144,7 +144,7 @@ class GLUConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         x, weight = _c(x), _c(weight)
         M, Cin, KS = weight.shape
-        u, _, _ = H.conv_nn(x, H.pack_conv_fwd(weight), M, KS, 1, bias=bias, want_pre=True,
+        u, _, _ = H.conv_nn(x, H.pack_conv_fwd(weight, (x.shape[2], 1)), M, KS, 1, bias=bias, want_pre=True,
                             want_out=False)
         out = H.glu_fwd(u)
         ctx.save_for_backward(x, weight, u)
@@ -158,7 +158,7 @@ class GLUConvFn(torch.autograd.Function):
         du, dbias = H.glu_bwd(_c(dout), u, want_dbias=ctx.has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
-            _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight), Cin, KS, 1)
+            _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight, (du.shape[2], 1)), Cin, KS, 1)
         dw = H.gemm_nt(du, x, x.shape[0], M, Cin, x.shape[2], KS, 1).view(weight.shape) \
             if ctx.needs_input_grad[1] else None
         return dx, dw, dbias
@@ -174,7 +174,7 @@ class SubjectLayersFn(torch.autograd.Function):
         x, weights = _c(x), _c(weights)
         S, C, D = weights.shape
         widx = H.index_i32(_c(subjects.to(torch.int64)), S)      # range-checked like the reference's gather
-        wp = H.pack_weights(weights, S, D, C, 1, C * D, 1, D, 0)
+        wp = H.pack_weights(weights, S, D, C, 1, C * D, 1, D, 0, shape=(x.shape[2], 1))
         _, out, _ = H.conv_nn(x, wp, D, 1, 1, widx=widx)
         ctx.save_for_backward(x, weights, subjects, widx)
         return out
@@ -187,7 +187,7 @@ class SubjectLayersFn(torch.autograd.Function):
         B, _, T = x.shape
         dx = None
         if ctx.needs_input_grad[0]:
-            wpt = H.pack_weights(weights, S, C, D, 1, C * D, D, 1, 0)
+            wpt = H.pack_weights(weights, S, C, D, 1, C * D, D, 1, 0, shape=(T, 1))
             _, dx, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=widx)
         dw = None
         if ctx.needs_input_grad[1]:
@@ -214,7 +214,7 @@ class ChannelMergerFn(torch.autograd.Function):
                            G=U, force_f32=True).view(U, O, C)
         weights = H.masked_softmax(scores, positions_u, ban_center, ban_radius)
         widx = H.index_i32(_c(layout_index.to(torch.int64)), U)
-        wp = H.pack_weights(weights, U, O, C, 1, O * C, C, 1, 0)
+        wp = H.pack_weights(weights, U, O, C, 1, O * C, C, 1, 0, shape=(meg.shape[2], 1))
         _, out, _ = H.conv_nn(meg, wp, O, 1, 1, widx=widx)
         ctx.save_for_backward(meg, emb, weights, layout_index, widx)
         ctx.dims = (U, C, O, D)
@@ -231,13 +231,13 @@ class ChannelMergerFn(torch.autograd.Function):
             order, seg = H.group_by_index(_c(layout_index.to(torch.int64)), U)
             dweights = H.gemm_nt(dout, meg, B, O, C, T, 1, 1, order=order, seg=seg, G=U).view(U, O, C)
             dscores = H.softmax_bwd(weights, dweights)
-            wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0)
+            wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0, shape=(D, 1))
             uidx = torch.arange(U, dtype=torch.int32, device=meg.device)
             _, per_layout, _ = H.conv_nn(emb, wp, O, 1, 1, widx=uidx)        # [U, O, D]
             dheads = H.sum_over_batch(per_layout) if U > 1 else per_layout[0]
         dmeg = None
         if ctx.needs_input_grad[0]:
-            wpt = H.pack_weights(weights, U, C, O, 1, O * C, 1, C, 0)
+            wpt = H.pack_weights(weights, U, C, O, 1, O * C, 1, C, 0, shape=(T, 1))
             _, dmeg, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=widx)
         return dmeg, dheads, None, None, None, None
 
@@ -274,14 +274,14 @@ class ClipLossFn(torch.autograd.Function):
         alpha = _c(dloss).view(1)
         dest = None
         if ctx.needs_input_grad[0]:
-            wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=alpha)
+            wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=alpha, shape=(K, 1))
             _, dest, _ = H.conv_nn(candidate.view(1, Bc, K), wp, B, 1, 1)
             dest = dest.view(ctx.shape)
         dcand = None
         if ctx.needs_input_grad[1]:
             # learnable candidates (DeepMel feature model): dcand_o = sum_b dscaled[b,o] est_b - coef_o cand_o
             estimate, scores, inv = ctx.saved_tensors[2:]
-            wpt = H.pack_weights(dscaled, 1, Bc, B, 1, 0, 1, Bc, 0, alpha=alpha)
+            wpt = H.pack_weights(dscaled, 1, Bc, B, 1, 0, 1, Bc, 0, alpha=alpha, shape=(K, 1))
             _, dcand, _ = H.conv_nn(estimate.view(1, B, K), wpt, Bc, 1, 1)
             coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
             H.row_axpy_sub(dcand.view(Bc, K), candidate.view(Bc, K), coef)

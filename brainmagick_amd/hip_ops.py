@@ -16,14 +16,19 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 BKC = 16
 
 # Compute mode of the MFMA contractions.  Activations / parameters / gradients stay fp32 in HBM.
-#   "f32x3" (default) fp32-ACCURATE contraction on the bf16 matrix cores: both fp32 operands are split
+#   "f16x2" fp32-ACCURATE contraction on the f16 matrix cores: every operand is scaled by a power of two (per
+#           tensor for activations, per output row for weights) and split into TWO f16 planes, three partial
+#           products per block, fp32 accumulate, exact inverse scaling; half the matrix-core work of "f32x3",
+#           same parity tolerances (norm-wise error bound, see csrc/conv_nn_h2w.hip).  Shapes the wide f16x2
+#           kernels do not cover run on the "f32x3" kernels;
+#   "f32x3" fp32-ACCURATE contraction on the bf16 matrix cores: both fp32 operands are split
 #           EXACTLY into three bf16 planes, six partial products per block, fp32 accumulate; measured
 #           error vs fp64 <= the exact-fp32 MFMA path's, held to the same parity tolerances;
 #   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
 #   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
 DEFAULT_COMPUTE_DTYPE = "f32x3"
-COMPUTE_DTYPES = ("f32", "f32x3", "bf16")
+COMPUTE_DTYPES = ("f32", "f32x3", "f16x2", "bf16")
 _compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE)
 if _compute_dtype not in COMPUTE_DTYPES:
     raise ValueError(f"BM_COMPUTE_DTYPE must be one of {COMPUTE_DTYPES}, got {_compute_dtype!r}")
@@ -105,17 +110,48 @@ def conv_mpad(M: int) -> int:
     return lib().bm_conv_mpad(M)
 
 
+def amax(x: torch.Tensor) -> torch.Tensor:
+    """[1] fp32 tensor holding max |x| (device side, no sync).  Cached on the tensor object together with
+    its version counter, so a tensor consumed by several contractions (forward conv, weight gradient) is
+    scanned once and an in-place modification invalidates the cache."""
+    cached = getattr(x, "_bm_amax", None)
+    if cached is not None and cached[0] == x._version and cached[1] == x.data_ptr():
+        return cached[2]
+    _req(x, "amax.x")
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib().bm_amax(_p(x), x.numel(), _p(out), _stream()), "bm_amax")
+    try:
+        x._bm_amax = (x._version, x.data_ptr(), out)
+    except Exception:       # tensors that refuse attributes: just do not cache
+        pass
+    return out
+
+
 def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, sm: int, sc: int,
-                 sj: int, flip: bool = False, alpha: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                 sj: int, flip: bool = False, alpha: tp.Optional[torch.Tensor] = None,
+                 shape: tp.Optional[tp.Tuple[int, int]] = None) -> torch.Tensor:
+    """``shape`` = (T, dilation) of the conv that will consume the packed weights: in "f16x2" mode it decides
+    between the wide f16x2 kernel's layout and the 3 x bf16 layout of the narrow kernels."""
     _req(src, "pack_weights.src")
-    if _compute_dtype in ("bf16", "f32x3"):
-        x3 = _compute_dtype == "f32x3"
+    mode = _compute_dtype
+    if mode == "f16x2":
+        if shape is not None and lib().bm_conv_h2_covers(Cin, M, shape[0], KS, shape[1]):
+            nbytes = lib().bm_packed_weight_bytes_h2(G, M, Cin, KS)
+            dst = torch.empty(nbytes, device=src.device, dtype=torch.uint8)
+            check(lib().bm_pack_weights_h2(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
+                                           _p(_opt(alpha, "alpha")), _stream()), "bm_pack_weights_h2")
+            dst._bm_mode = "f16x2"
+            dst._bm_groups = G
+            return dst
+        mode = "f32x3"
+    if mode in ("bf16", "f32x3"):
+        x3 = mode == "f32x3"
         n = (lib().bm_packed_weight_elems_x3 if x3 else lib().bm_packed_weight_elems_bf16)(G, M, Cin, KS)
         dst = torch.empty(n, device=src.device, dtype=torch.bfloat16)
         fn = lib().bm_pack_weights_x3 if x3 else lib().bm_pack_weights_bf16
         check(fn(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip), _p(_opt(alpha, "alpha")),
                  _stream()), "bm_pack_weights_x3" if x3 else "bm_pack_weights_bf16")
-        dst._bm_mode = _compute_dtype            # tells conv_nn which kernel family packed it
+        dst._bm_mode = mode                      # tells conv_nn which kernel family packed it
         return dst
     n = lib().bm_packed_weight_elems(G, M, Cin, KS)
     dst = torch.empty(n, device=src.device, dtype=torch.float32)
@@ -124,16 +160,16 @@ def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, 
     return dst
 
 
-def pack_conv_fwd(weight: torch.Tensor) -> torch.Tensor:
+def pack_conv_fwd(weight: torch.Tensor, shape=None) -> torch.Tensor:
     """nn.Conv1d weight [M, Cin, KS] for the forward conv."""
     M, Cin, KS = weight.shape
-    return pack_weights(weight, 1, M, Cin, KS, 0, Cin * KS, KS, 1)
+    return pack_weights(weight, 1, M, Cin, KS, 0, Cin * KS, KS, 1, shape=shape)
 
 
-def pack_conv_dgrad(weight: torch.Tensor) -> torch.Tensor:
+def pack_conv_dgrad(weight: torch.Tensor, shape=None) -> torch.Tensor:
     """nn.Conv1d weight [M, Cin, KS] for the data gradient: roles of M/Cin swapped, taps flipped."""
     M, Cin, KS = weight.shape
-    return pack_weights(weight, 1, Cin, M, KS, 0, KS, Cin * KS, 1, flip=True)
+    return pack_weights(weight, 1, Cin, M, KS, 0, KS, Cin * KS, 1, flip=True, shape=shape)
 
 
 def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: int = 1,
@@ -143,8 +179,7 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T]."""
     _req(x, "conv_nn.x")
     mode = getattr(wpacked, "_bm_mode", "f32")      # set by pack_weights
-    bf16 = mode != "f32"
-    _req(wpacked, "conv_nn.w", torch.bfloat16 if bf16 else torch.float32)
+    _req(wpacked, "conv_nn.w", {"f32": torch.float32, "f16x2": torch.uint8}.get(mode, torch.bfloat16))
     B, Cin, T = x.shape
     y_pre = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_pre else None
     y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
@@ -155,65 +190,34 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))
-    fn = {"f32": lib().bm_conv1d_nn, "bf16": lib().bm_conv1d_nn_bf16,
-          "f32x3": lib().bm_conv1d_nn_x3}[mode]
+    common = (_p(_opt(widx, "widx", torch.int32)), _p(_opt(bias, "bias")), _p(_opt(scale, "scale")),
+              _p(_opt(shift, "shift")), _p(res), M * T, _p(y_pre), _p(y_out), M * T, _p(stats), B, Cin, M, T,
+              KS, dil, act, leak)
+    if mode == "f16x2":
+        x_amax = amax(x)
 
-    def launch():
-        check(fn(_p(x), Cin * T, _p(wpacked), _p(_opt(widx, "widx", torch.int32)),
-                 _p(_opt(bias, "bias")), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")), _p(res),
-                 M * T, _p(y_pre), _p(y_out), M * T, _p(stats), B, Cin, M, T, KS, dil, act, leak,
-                 _stream()), f"bm_conv1d_nn[{mode}]")
+        def launch():
+            check(lib().bm_conv1d_nn_h2(_p(x), Cin * T, _p(x_amax), _p(wpacked), *common, wpacked._bm_groups,
+                                        _stream()), "bm_conv1d_nn_h2")
+    else:
+        fn = {"f32": lib().bm_conv1d_nn, "bf16": lib().bm_conv1d_nn_bf16,
+              "f32x3": lib().bm_conv1d_nn_x3}[mode]
+
+        def launch():
+            check(fn(_p(x), Cin * T, _p(wpacked), *common, _stream()), f"bm_conv1d_nn[{mode}]")
     if _timer is not None:
-        label = {"f32": f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>",
-                 "bf16": f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>",
-                 "f32x3": (f"conv_nn_x3w_kernel<{KS}>"
-                           if mode == "f32x3" and lib().bm_conv_x3_is_wide(Cin, M, T, KS, dil, int(want_stats))
-                           else f"conv_nn_x3_kernel<{lib().bm_conv_bf16_mt_for(M)}>")}[mode]
+        if mode == "f16x2":
+            label = f"conv_nn_h2w_kernel<{KS},{lib().bm_conv_h2_mw_for(M)}>"
+        else:
+            label = {"f32": f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>",
+                     "bf16": f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>",
+                     "f32x3": (f"conv_nn_x3w_kernel<{KS}>"
+                               if mode == "f32x3" and lib().bm_conv_x3_is_wide(Cin, M, T, KS, dil, int(want_stats))
+                               else f"conv_nn_x3_kernel<{lib().bm_conv_bf16_mt_for(M)}>")}[mode]
         _timer.launch(label, 2.0 * B * T * M * Cin * KS, launch)
     else:
         launch()
     return y_pre, y_out, stats
-
-
-# Device-side "index out of range" flag (one int32 per device).  The grouped kernels never read outside
-# their weight tables (bad indices are clamped to group 0 by bm_index_to_i32 / skipped by
-# bm_group_by_index); the flag is raised as an IndexError at the next synchronisation point the caller
-# chooses (`raise_if_index_error`, called by Solver next to the reference's isfinite asserts), or
-# immediately with BM_CHECK_INDICES=1.
-_index_err: tp.Dict[torch.device, torch.Tensor] = {}
-_CHECK_INDICES_NOW = _os.environ.get("BM_CHECK_INDICES", "0") == "1"
-
-
-def index_error_flag(device) -> torch.Tensor:
-    device = torch.device(device)
-    if device.index is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    flag = _index_err.get(device)
-    if flag is None:
-        flag = torch.zeros(1, device=device, dtype=torch.int32)
-        _index_err[device] = flag
-    return flag
-
-
-def raise_if_index_error(device=None):
-    """Synchronising check of the flag; raises like the reference's out-of-range gather would."""
-    flags = list(_index_err.values()) if device is None else [index_error_flag(device)]
-    for flag in flags:
-        if int(flag.item()) != 0:
-            flag.zero_()
-            raise IndexError("subject / layout index out of range for the weight table "
-                             "(bm/models/common.py:57 would raise in `weights.gather`)")
-
-
-def index_i32(idx: torch.Tensor, G: int) -> torch.Tensor:
-    """idx [B] int64 -> int32 group indices, range-checked against [0, G) on the device."""
-    _req(idx, "index_i32.idx", torch.int64)
-    out = torch.empty(idx.numel(), device=idx.device, dtype=torch.int32)
-    check(lib().bm_index_to_i32(_p(idx), idx.numel(), G, _p(out), _p(index_error_flag(idx.device)),
-                                _stream()), "bm_index_to_i32")
-    if _CHECK_INDICES_NOW:
-        raise_if_index_error(idx.device)
-    return out
 
 
 def group_by_index(idx: torch.Tensor, G: int):
@@ -249,6 +253,8 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
     if out is None:
         out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
     mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
+    if mode == "f16x2":
+        mode = "f32x3"          # shapes without a wide f16x2 kernel: the (equally fp32-accurate) 3 x bf16 kernels
     if nsplit is None:
         if mode == "f32x3" and order is None:
             nsplit = lib().bm_gemm_nt_x3_suggest_splits(M, Cn, KS, S, T, G, dil)
@@ -287,13 +293,14 @@ def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
         nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, 1, S, T, 1)
     part = torch.empty(nsplit, M, Cn, device=a.device, dtype=torch.float32)
     # scores feed a softmax: exact fp32 or the fp32-accurate x3 path, never plain bf16
-    fn = lib().bm_gemm_nt_x3 if _compute_dtype == "f32x3" else lib().bm_gemm_nt
+    x3 = _compute_dtype in ("f32x3", "f16x2")
+    fn = lib().bm_gemm_nt_x3 if x3 else lib().bm_gemm_nt
 
     def launch():
         check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1], None, None, _p(part),
                  S, 1, M, Cn, T, 1, 1, nsplit, _stream()), "bm_gemm_nt")
     if _timer is not None:
-        _timer.launch("clip_scores:gemm_nt" + ("_x3" if _compute_dtype == "f32x3" else ""),
+        _timer.launch("clip_scores:gemm_nt" + ("_x3" if x3 else ""),
                       2.0 * S * T * M * Cn, launch)
     else:
         launch()

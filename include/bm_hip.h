@@ -98,6 +98,24 @@ int bm_gemm_nt_bf16(const float* a, long a_sstride, long a_rstride, const float*
                     long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                     int Cn, int T, int KS, int dil, int nsplit, void* stream);
 
+/* ---- fp32-ACCURATE contraction on the f16 matrix cores, compute mode "f16x2" (conv_nn_h2w.hip): every operand
+ * is scaled by a power of two (per tensor for activations, per output row for weights) and split into two f16
+ * planes; three partial products per MFMA block, fp32 accumulate, exact inverse scaling in the epilogue.  Half
+ * the matrix-core work of "f32x3" at the same parity tolerances.  Same conv contract as bm_conv1d_nn plus
+ * `x_amax` (device pointer to max|x| of the input tensor, e.g. from bm_amax) and G (weight groups packed).
+ * Shapes bm_conv_h2_covers() rejects go through bm_conv1d_nn_x3 (also fp32-accurate). */
+int bm_conv_h2_mw_for(int M);
+int bm_conv_h2_mpad(int M);
+int bm_conv_h2_covers(int Cin, int M, int T, int KS, int dil);
+long bm_packed_weight_bytes_h2(int G, int M, int Cin, int KS);
+int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm, long sc,
+                       long sj, int flip, const float* alpha_ptr, void* stream);
+int bm_amax(const float* x, long n, float* out, void* stream);
+int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked, const int* widx,
+                    const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                    long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B, int Cin,
+                    int M, int T, int KS, int dil, int act, float leak, int G, void* stream);
+
 /* ---- time-contraction GEMM, fp32 MFMA, split-K (gemm_nt.hip) ----
  * part[g,split][m][c*KS+j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j-KS/2)*dil].
  * Replaces aten::convolution_backward (weight part), the weight-grad einsums of SubjectLayers /

@@ -1,0 +1,213 @@
+"""Compute mode "f16x2": fp32-accurate contractions on the f16 matrix cores (per-tensor / per-row power-of-two
+scaling, two f16 planes per operand, three partial products, fp32 accumulate -- csrc/conv_nn_h2w.hip,
+csrc/gemm_nt_h2w.hip).  Held to the SAME tolerances as the exact-fp32 MFMA mode: per-kernel forward rel-L2
+<= 5e-6 vs fp64, gradients <= 2e-5, end-to-end 1e-5 / 1e-4 / loss 1e-4; the kernel, golden-vector, oracle and
+training-curve suites are re-run in this mode, and its error vs fp64 is compared with the other modes'."""
+import math
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+import test_kernels_gpu as TK
+import test_model_gpu as TM
+from helpers import rel_l2, MODEL_FIXTURES
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = TK.FWD_TOL
+GRAD_TOL = TK.GRAD_TOL
+
+
+@pytest.fixture()
+def h2_mode():
+    import brainmagick_amd
+    default = brainmagick_amd.get_compute_dtype()
+    brainmagick_amd.set_compute_dtype("f16x2")
+    yield
+    brainmagick_amd.set_compute_dtype(default)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from brainmagick_amd import hip_ops
+    return hip_ops
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# Cin, M, KS, dil, T, B -- every MW variant of the wide kernel (M -> 64 MW row tiles, MW in {5, 4, 2}), padded
+# rows / channels, both kernel sizes, tile-boundary lengths, plus the generic cases (some fall to the narrow kernels)
+H2_CASES = TK.CONV_CASES + [
+    (270, 270, 1, 1, 360, 2),      # the 270-channel front end: MW = 5, 50 padded rows
+    (208, 270, 1, 1, 361, 2),      # merger apply
+    (270, 208, 1, 1, 343, 2),      # its data gradient: MW = 4 (256 rows)
+    (640, 120, 1, 1, 360, 2),      # mel head: MW = 2 (128 rows)
+    (640, 1024, 1, 1, 200, 1),     # wav2vec head: MW = 4, four row tiles
+    (256, 256, 1, 1, 1200, 1),     # ClipLoss dEst shape (long time axis, one segment)
+    (320, 320, 3, 8, 193, 2),      # second time tile holds one column
+    (24, 128, 3, 1, 130, 3),       # MW = 2 with 3 taps
+]
+
+
+def _covered(H, Cin, M, T, KS, dil):
+    return bool(H.lib().bm_conv_h2_covers(Cin, M, T, KS, dil))
+
+
+@pytest.mark.parametrize("Cin,M,KS,dil,T,B", H2_CASES)
+def test_conv_forward(h2_mode, H, Cin, M, KS, dil, T, B):
+    g = _gen(Cin * 7 + M + KS + dil + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
+    b = torch.randn(M, generator=g)
+    ref = F.conv1d(x.double(), w.double(), b.double(), padding=KS // 2 * dil, dilation=dil)
+    wp = H.pack_conv_fwd(w.cuda(), (T, dil))
+    assert wp._bm_mode == ("f16x2" if _covered(H, Cin, M, T, KS, dil) else "f32x3")
+    _, y, _ = H.conv_nn(x.cuda(), wp, M, KS, dil, bias=b.cuda())
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < FWD_TOL
+
+
+def test_wide_kernel_is_what_runs_for_the_paper_shapes(H, h2_mode):
+    for Cin, M, KS, dil, T in [(270, 320, 3, 1, 360), (320, 320, 3, 16, 343), (320, 640, 3, 1, 361),
+                               (320, 640, 1, 1, 360), (640, 120, 1, 1, 360), (208, 270, 1, 1, 360),
+                               (270, 270, 1, 1, 360), (256, 256, 1, 1, 43200)]:
+        assert _covered(H, Cin, M, T, KS, dil), (Cin, M, KS, dil, T)
+    assert not _covered(H, 320, 320, 3, 32, 360)       # halo beyond the staged window
+    assert not _covered(H, 16, 16, 3, 4, 7)
+
+
+@pytest.mark.parametrize("M,KS", [(320, 3), (256, 1), (128, 3), (270, 1)])
+def test_conv_epilogues(h2_mode, H, M, KS):
+    """bias / pre-activation store / per-channel affine / exact-erf GELU / residual in the wide kernel's general
+    epilogue, against fp64."""
+    g = _gen(M + KS)
+    B, Cin, T, dil = 2, 64, 300, 2
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
+    b = torch.randn(M, generator=g)
+    scale = torch.rand(M, generator=g) + 0.5
+    shift = torch.randn(M, generator=g)
+    res = torch.randn(B, M, T, generator=g)
+    pre_ref = F.conv1d(x.double(), w.double(), b.double(), padding=KS // 2 * dil, dilation=dil)
+    out_ref = F.gelu(pre_ref * scale.double()[None, :, None] + shift.double()[None, :, None]) + res.double()
+    wp = H.pack_conv_fwd(w.cuda(), (T, dil))
+    assert wp._bm_mode == "f16x2"
+    pre, out, _ = H.conv_nn(x.cuda(), wp, M, KS, dil, bias=b.cuda(), scale=scale.cuda(), shift=shift.cuda(),
+                            res=res.cuda(), act=H.ACT_GELU, want_pre=True)
+    assert rel_l2(pre, pre_ref) < FWD_TOL and rel_l2(out, out_ref) < FWD_TOL
+    # the simple epilogue (one output, optional residual)
+    _, out2, _ = H.conv_nn(x.cuda(), wp, M, KS, dil, bias=b.cuda(), res=res.cuda())
+    assert rel_l2(out2, pre_ref + res.double()) < FWD_TOL
+    pre3, none, _ = H.conv_nn(x.cuda(), wp, M, KS, dil, want_pre=True, want_out=False)
+    assert none is None and rel_l2(pre3, pre_ref - b.double()[None, :, None]) < FWD_TOL
+
+
+def test_amax_kernel(H):
+    g = _gen(1)
+    for n in (1, 5, 1024, 4 * 1000 + 3, 3 * 208 * 360):
+        x = torch.randn(n, generator=g) * 3
+        got = H.amax(x.cuda())
+        assert float(got) == float(x.abs().max())
+    x = torch.zeros(64).cuda()
+    assert float(H.amax(x)) == 0.0
+    # cached per tensor version: an in-place change invalidates the cache
+    y = torch.ones(1000).cuda()
+    a1 = H.amax(y)
+    assert H.amax(y) is a1
+    y.mul_(5)
+    assert float(H.amax(y)) == 5.0
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-6, 1.0), (300.0, 1e-4), (1.0, 1e5), (2 ** -40, 2 ** 30)])
+def test_dynamic_range_is_handled_by_the_scales(h2_mode, H, xs, ws):
+    """f16 has 5 exponent bits: tensors far from 1 in magnitude (tiny gradients, large weights) must come out
+    with the same relative accuracy, and weight rows of very different magnitude (per-row scale) too."""
+    g = _gen(7)
+    B, Cin, M, KS, dil, T = 2, 96, 320, 3, 1, 256
+    x = torch.randn(B, Cin, T, generator=g) * xs
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS) * ws
+    w = w * torch.logspace(-6, 6, M)[:, None, None]          # rows spanning 12 decades
+    ref = F.conv1d(x.double(), w.double(), None, padding=dil, dilation=dil)
+    _, y, _ = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda(), (T, dil)), M, KS, dil)
+    # per output row (every row has its own scale): relative error at the fp32 level
+    err = (y.double().cpu() - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))
+    assert err.max().item() < FWD_TOL, err.max().item()
+
+
+def test_nonfinite_inputs_do_not_turn_finite(h2_mode, H):
+    g = _gen(3)
+    x = torch.randn(1, 32, 200, generator=g)
+    x[0, 3, 17] = float("inf")
+    w = torch.randn(128, 32, 1, generator=g)
+    _, y, _ = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda(), (200, 1)), 128, 1, 1)
+    assert not torch.isfinite(y[0, :, 17]).any()
+
+
+def test_error_is_fp32_class(H):
+    """rel-L2 vs fp64 of the three fp32-class modes on the same conv / weight gradient (K = 960 and 92 160)."""
+    import brainmagick_amd
+    g = _gen(0)
+    B, Cin, M, KS, dil, T = 4, 320, 320, 3, 2, 360
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
+    dy = torch.randn(B, M, T, generator=g)
+    ref = F.conv1d(x.double(), w.double(), None, padding=dil, dilation=dil)
+    wg = torch.zeros(M, Cin, KS, dtype=torch.float64, requires_grad=True)
+    F.conv1d(x.double(), wg, None, padding=dil, dilation=dil).backward(dy.double())
+    default = brainmagick_amd.get_compute_dtype()
+    errs = {}
+    for mode in ("f32", "f32x3", "f16x2"):
+        brainmagick_amd.set_compute_dtype(mode)
+        try:
+            _, y, _ = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda(), (T, dil)), M, KS, dil)
+            dw = H.gemm_nt(dy.cuda(), x.cuda(), B, M, Cin, T, KS, dil)[0]
+        finally:
+            brainmagick_amd.set_compute_dtype(default)
+        errs[mode] = (rel_l2(y, ref), rel_l2(dw, wg.grad))
+    print("rel-L2 vs fp64 (conv fwd, wgrad):", errs)
+    for k in range(2):
+        assert errs["f16x2"][k] < 1e-6
+        assert errs["f16x2"][k] < 3 * errs["f32"][k] + 1e-7
+
+
+@pytest.mark.parametrize("Cin,M,KS,dil,T,B", TK.CONV_CASES[:7] + [(320, 320, 3, 2, 360, 4), (128, 640, 3, 1, 361, 3)])
+def test_conv_backward(h2_mode, H, Cin, M, KS, dil, T, B):
+    TK.test_conv_backward_kernels(H, Cin, M, KS, dil, T, B)
+
+
+def test_subject_layers_and_merger(h2_mode, H):
+    TK.test_subject_layers_kernels(H)
+    TK.test_merger_kernels(H)
+
+
+@pytest.mark.parametrize("B,Bc,Fd,T", [(6, 6, 10, 48), (5, 12, 7, 33), (64, 64, 120, 360)])
+def test_clip(h2_mode, H, B, Bc, Fd, T):
+    TK.test_clip_kernels(H, B, Bc, Fd, T)
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_reference_golden(h2_mode, name):
+    TM.test_against_reference_golden(name)
+
+
+@pytest.mark.parametrize("cfg_name,B,T", [("cfg2", 8, 360), ("cfg5", 6, 343), ("cfg1", 4, 361)])
+def test_paper_model_step(h2_mode, cfg_name, B, T):
+    TM.test_paper_model_step_against_oracle(cfg_name, B, T)
+
+
+@pytest.mark.parametrize("cfg_name,B", [("cfg2", 256), ("cfg3", 256)])
+def test_full_size_step(h2_mode, cfg_name, B):
+    TM.test_full_size_step_against_oracle(cfg_name, B)
+
+
+def test_training_curve(h2_mode):
+    TM.test_training_curve_and_top10_parity()
+
+
+def test_deep_mel_and_edge_shapes(h2_mode):
+    TM.test_deep_mel_feature_model_step()
+    for B, T in [(1, 360), (5, 129)]:
+        TM.test_edge_shapes_against_oracle(B, T)
