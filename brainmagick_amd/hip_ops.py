@@ -16,7 +16,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 BKC = 16
 
 # Compute mode of the MFMA contractions.  Activations / parameters / gradients stay fp32 in HBM.
-#   "f16x2" fp32-ACCURATE contraction on the f16 matrix cores: every operand is scaled by a power of two (per
+#   "f16x2" (default) fp32-ACCURATE contraction on the f16 matrix cores: every operand is scaled by a power of two (per
 #           tensor for activations, per output row for weights) and split into TWO f16 planes, three partial
 #           products per block, fp32 accumulate, exact inverse scaling; half the matrix-core work of "f32x3",
 #           same parity tolerances (norm-wise error bound, see csrc/conv_nn_h2w.hip).  Shapes the wide f16x2
@@ -27,7 +27,7 @@ BKC = 16
 #   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
 #   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
-DEFAULT_COMPUTE_DTYPE = "f32x3"
+DEFAULT_COMPUTE_DTYPE = "f16x2"
 COMPUTE_DTYPES = ("f32", "f32x3", "f16x2", "bf16")
 _compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE)
 if _compute_dtype not in COMPUTE_DTYPES:
@@ -220,6 +220,47 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     return y_pre, y_out, stats
 
 
+# Device-side "index out of range" flag (one int32 per device).  The grouped kernels never read outside
+# their weight tables (bad indices are clamped to group 0 by bm_index_to_i32 / skipped by
+# bm_group_by_index); the flag is raised as an IndexError at the next synchronisation point the caller
+# chooses (`raise_if_index_error`, called by Solver next to the reference's isfinite asserts), or
+# immediately with BM_CHECK_INDICES=1.
+_index_err: tp.Dict[torch.device, torch.Tensor] = {}
+_CHECK_INDICES_NOW = _os.environ.get("BM_CHECK_INDICES", "0") == "1"
+
+
+def index_error_flag(device) -> torch.Tensor:
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    flag = _index_err.get(device)
+    if flag is None:
+        flag = torch.zeros(1, device=device, dtype=torch.int32)
+        _index_err[device] = flag
+    return flag
+
+
+def raise_if_index_error(device=None):
+    """Synchronising check of the flag; raises like the reference's out-of-range gather would."""
+    flags = list(_index_err.values()) if device is None else [index_error_flag(device)]
+    for flag in flags:
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError("subject / layout index out of range for the weight table "
+                             "(bm/models/common.py:57 would raise in `weights.gather`)")
+
+
+def index_i32(idx: torch.Tensor, G: int) -> torch.Tensor:
+    """idx [B] int64 -> int32 group indices, range-checked against [0, G) on the device."""
+    _req(idx, "index_i32.idx", torch.int64)
+    out = torch.empty(idx.numel(), device=idx.device, dtype=torch.int32)
+    check(lib().bm_index_to_i32(_p(idx), idx.numel(), G, _p(out), _p(index_error_flag(idx.device)),
+                                _stream()), "bm_index_to_i32")
+    if _CHECK_INDICES_NOW:
+        raise_if_index_error(idx.device)
+    return out
+
+
 def group_by_index(idx: torch.Tensor, G: int):
     """idx [B] int64 -> (order [B] int32, seg [G+1] int32)."""
     _req(idx, "group_by_index.idx", torch.int64)
@@ -254,7 +295,11 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
     mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
     if mode == "f16x2":
-        mode = "f32x3"          # shapes without a wide f16x2 kernel: the (equally fp32-accurate) 3 x bf16 kernels
+        contiguous = tuple(a_strides) == (M * T, T) and tuple(x_strides) == (Cn * T, T)
+        if not (contiguous and lib().bm_gemm_nt_h2_covers(M, Cn, KS, S, T, G, dil, int(order is not None))):
+            mode = "f32x3"      # shapes without a wide f16x2 kernel: the (equally fp32-accurate) 3 x bf16 kernels
+        elif nsplit is None:
+            nsplit = lib().bm_gemm_nt_h2_suggest_splits(M, Cn, KS, S, T)
     if nsplit is None:
         if mode == "f32x3" and order is None:
             nsplit = lib().bm_gemm_nt_x3_suggest_splits(M, Cn, KS, S, T, G, dil)
@@ -268,14 +313,22 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = out
     else:
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
-    fn = {"f32": lib().bm_gemm_nt, "bf16": lib().bm_gemm_nt_bf16, "f32x3": lib().bm_gemm_nt_x3}[mode]
+    if mode == "f16x2":
+        a_amax, x_amax = amax(a), amax(x)
 
-    def launch():
-        check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
-                 _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)), _p(part), S,
-                 G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
+        def launch():
+            check(lib().bm_gemm_nt_h2(_p(a), a_strides[0], a_strides[1], _p(a_amax), _p(x), x_strides[0],
+                                      x_strides[1], _p(x_amax), _p(part), S, M, Cn, T, KS, dil, nsplit,
+                                      _stream()), "bm_gemm_nt_h2")
+    else:
+        fn = {"f32": lib().bm_gemm_nt, "bf16": lib().bm_gemm_nt_bf16, "f32x3": lib().bm_gemm_nt_x3}[mode]
+
+        def launch():
+            check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
+                     _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)), _p(part), S,
+                     G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
     if _timer is not None:
-        suffix = {"f32": "", "bf16": "_bf16", "f32x3": "_x3"}[mode]
+        suffix = {"f32": "", "bf16": "_bf16", "f32x3": "_x3", "f16x2": "_h2w"}[mode]
         _timer.launch(f"gemm_nt{suffix}_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS, launch)
     else:
         launch()

@@ -116,6 +116,15 @@ int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const v
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B, int Cin,
                     int M, int T, int KS, int dil, int act, float leak, int G, void* stream);
 
+/* f16x2 weight gradients (gemm_nt_h2w.hip): part[split][m][c*KS + j] over S consecutive segments, one group,
+ * KS in {1, 3}; a_amax / x_amax = device pointers to max|a| / max|x| (bm_amax).  Shapes bm_gemm_nt_h2_covers()
+ * rejects (grouped / ordered calls, tiny shapes) go through bm_gemm_nt_x3. */
+int bm_gemm_nt_h2_covers(int M, int Cn, int KS, int S, int T, int G, int dil, int ordered);
+int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T);
+int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* x,
+                  long x_sstride, long x_rstride, const float* x_amax, float* part, int S, int M, int Cn, int T,
+                  int KS, int dil, int nsplit, void* stream);
+
 /* ---- time-contraction GEMM, fp32 MFMA, split-K (gemm_nt.hip) ----
  * part[g,split][m][c*KS+j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j-KS/2)*dil].
  * Replaces aten::convolution_backward (weight part), the weight-grad einsums of SubjectLayers /

@@ -1,10 +1,11 @@
-"""The two fp32-class compute modes side by side.
+"""The fp32-class compute modes side by side.
 
-The library default is "f32x3": fp32-ACCURATE contractions on the bf16 matrix cores (exact 3-way bf16
-split of both operands, six partial products, fp32 accumulate); every other GPU test file runs in it.
-This file re-runs the kernel, golden-vector and oracle suites in the OTHER mode, "f32" (exact-fp32 MFMA,
-v_mfma_f32_32x32x2_f32), at the SAME tolerances -- per-kernel forward rel-L2 <= 5e-6 vs fp64, gradients
-<= 2e-5, end-to-end 1e-5 / 1e-4 / loss 1e-4 -- and compares the two modes' errors directly."""
+The library default is "f16x2" (fp32-accurate contractions on the f16 matrix cores: two scaled f16 planes per
+operand, three partial products, fp32 accumulate); every other GPU test file runs in it.  This file re-runs the
+kernel, golden-vector and oracle suites in the OTHER two fp32-class modes -- "f32" (exact-fp32 MFMA,
+v_mfma_f32_32x32x2_f32, bit-comparable to an fp32 FMA chain) and "f32x3" (exact 3-way bf16 split, six partial
+products) -- at the SAME tolerances: per-kernel forward rel-L2 <= 5e-6 vs fp64, gradients <= 2e-5, end-to-end
+1e-5 / 1e-4 / loss 1e-4 -- and compares the modes' errors directly."""
 import math
 
 import pytest
@@ -18,15 +19,15 @@ from helpers import rel_l2, MODEL_FIXTURES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def x3_mode():
-    """(historical name) switches to the exact-fp32 MFMA mode for the test, then back to the default."""
+@pytest.fixture(params=["f32", "f32x3"])
+def x3_mode(request):
+    """(historical name) switches to another fp32-class mode for the test, then back to the default."""
     import brainmagick_amd
     import os
     default = brainmagick_amd.get_compute_dtype()
     if "BM_COMPUTE_DTYPE" not in os.environ:
-        assert default == "f32x3"          # the library default (an explicit env override is respected)
-    brainmagick_amd.set_compute_dtype("f32")
+        assert default == "f16x2"          # the library default (an explicit env override is respected)
+    brainmagick_amd.set_compute_dtype(request.param)
     yield
     brainmagick_amd.set_compute_dtype(default)
 
@@ -60,13 +61,14 @@ def test_x3_error_is_fp32_class(H):
     wg = torch.zeros(M, Cin, KS, dtype=torch.float64, requires_grad=True)
     F.conv1d(x.double(), wg, None, padding=dil, dilation=dil).backward(dy.double())
     errs = {}
+    default = brainmagick_amd.get_compute_dtype()
     for mode in ("f32", "f32x3"):
         brainmagick_amd.set_compute_dtype(mode)
         try:
             _, y, _ = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda()), M, KS, dil)
             dw = H.gemm_nt(dy.cuda(), x.cuda(), B, M, Cin, T, KS, dil)[0]
         finally:
-            brainmagick_amd.set_compute_dtype("f32x3")
+            brainmagick_amd.set_compute_dtype(default)
         errs[mode] = (rel_l2(y, ref), rel_l2(dw, wg.grad))
     print("rel-L2 vs fp64 (conv fwd, wgrad):", errs)
     for k in range(2):

@@ -200,22 +200,59 @@ def test_data_parallel_exchange_world2_gloo(tmp_path):
         assert p.returncode == 0 and f"WORKER_OK {r}" in out, out
 
 
-def test_wide_kernels_do_not_spill(tmp_path):
-    """gemm_nt_x3w issues its staging loads through inline asm with hand-counted waits: a register the
-    compiler spilled (or re-used) while such a load is in flight would be silently corrupted, so the wide
-    kernels must compile without VGPR spills."""
+_WIDE = ("gemm_nt_x3w.hip", "conv_nn_x3w.hip", "gemm_nt_h2w.hip", "conv_nn_h2w.hip")
+_asm_cache = {}
+
+
+def _wide_kernel_asm():
+    """gfx950 assembly of the wide-tile kernels (compiled once per session, the four files in parallel)."""
+    import concurrent.futures
     import shutil
     import subprocess
+    import tempfile
+    if _asm_cache:
+        return _asm_cache
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
     csrc = ROOT / "brainmagick_amd" / "csrc"
-    for name in ("gemm_nt_x3w.hip", "conv_nn_x3w.hip"):
-        out = tmp_path / (name + ".s")
+    tmp = Path(tempfile.mkdtemp(prefix="bm_asm_"))
+
+    def one(name):
+        out = tmp / (name + ".s")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                         f"-I{csrc}", "-o", str(out), str(csrc / name)], check=True, capture_output=True)
-        spills = [int(l.split(":")[1]) for l in out.read_text().splitlines() if ".vgpr_spill_count" in l]
+        return name, out.read_text()
+    with concurrent.futures.ThreadPoolExecutor(4) as pool:
+        _asm_cache.update(dict(pool.map(one, _WIDE)))
+    return _asm_cache
+
+
+def test_wide_kernels_do_not_spill():
+    """The wide kernels keep 240 accumulators + operand fragments + staging sets in the 512-register file; a
+    spill would put scratch traffic (and, for the asm-issued loads, silent corruption) into the main loop."""
+    for name, text in _wide_kernel_asm().items():
+        spills = [int(l.split(":")[1]) for l in text.splitlines() if ".vgpr_spill_count" in l]
+        scratch = [int(l.split(":")[1]) for l in text.splitlines() if ".private_segment_fixed_size" in l]
         assert spills and all(s == 0 for s in spills), (name, spills)
+        assert all(s == 0 for s in scratch), (name, scratch)
+
+
+def test_hand_issued_loads_are_not_touched_before_their_wait():
+    """conv_nn_h2w / conv_nn_x3w issue the input-window loads through inline asm with hand-counted waits (a
+    compiler-visible load next to the LDS-DMA weight copies would drain the DMA queue at every use).  hipcc may
+    copy or re-use an asm load's destination register while the load is still in flight; scripts/audit_asm_loads.py
+    checks on the generated ISA that it does not.  (gemm_nt_h2w uses compiler-visible loads for exactly that
+    reason: there the allocator did copy an in-flight staging set.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_asm_loads", ROOT / "scripts" / "audit_asm_loads.py")
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    asm = _wide_kernel_asm()
+    for name in ("conv_nn_h2w.hip", "conv_nn_x3w.hip"):
+        violations = audit.audit_text(asm[name])
+        assert not violations, (name, violations[:5])
+    assert "buffer_load" not in "".join(l for l in asm["gemm_nt_h2w.hip"].splitlines() if "ASMSTART" in l)
 
 
 def test_deep_mel_known_answer_of_the_reference():

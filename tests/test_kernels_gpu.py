@@ -54,7 +54,7 @@ def test_conv_nn_forward(H, Cin, M, KS, dil, T, B):
     w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
     b = torch.randn(M, generator=g)
     ref = F.conv1d(x.double(), w.double(), b.double(), padding=KS // 2 * dil, dilation=dil)
-    wp = H.pack_conv_fwd(w.cuda())
+    wp = H.pack_conv_fwd(w.cuda(), (T, dil))
     _, y, _ = H.conv_nn(x.cuda(), wp, M, KS, dil, bias=b.cuda())
     assert y.shape == ref.shape
     assert rel_l2(y, ref) < FWD_TOL
@@ -74,7 +74,7 @@ def test_conv_nn_epilogue_and_stats(H):
                     (H.ACT_LEAKY, lambda z: F.leaky_relu(z, 0.1)), (H.ACT_NONE, lambda z: z)]:
         out_ref = fn(pre_ref * scale.double()[None, :, None] + shift.double()[None, :, None]) \
             + res.double()
-        pre, out, stats = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda()), M, KS, dil, bias=b.cuda(),
+        pre, out, stats = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda(), (x.shape[2], dil)), M, KS, dil, bias=b.cuda(),
                                     scale=scale.cuda(), shift=shift.cuda(), res=res.cuda(), act=act,
                                     leak=0.1, want_pre=True, want_stats=True)
         assert rel_l2(pre, pre_ref) < FWD_TOL
@@ -94,7 +94,7 @@ def test_conv_backward_kernels(H, Cin, M, KS, dil, T, B):
     y = F.conv1d(x, w, None, padding=KS // 2 * dil, dilation=dil)
     y.backward(dy)
     dyg, xg, wg = dy.float().cuda(), x.detach().float().cuda(), w.detach().float().cuda()
-    _, dx, _ = H.conv_nn(dyg, H.pack_conv_dgrad(wg), Cin, KS, dil)
+    _, dx, _ = H.conv_nn(dyg, H.pack_conv_dgrad(wg, (T, dil)), Cin, KS, dil)
     assert rel_l2(dx, x.grad) < GRAD_TOL
     dw = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil)
     assert dw.shape == (1, M, Cin, KS)
@@ -125,10 +125,10 @@ def test_subject_layers_kernels(H):
     ref.backward(dy)
     xg, Wg, dyg = x.detach().float().cuda(), W.detach().float().cuda(), dy.float().cuda()
     widx = subj.to(torch.int32).cuda()
-    wp = H.pack_weights(Wg, S, D, C, 1, C * D, 1, D, 0)
+    wp = H.pack_weights(Wg, S, D, C, 1, C * D, 1, D, 0, shape=(T, 1))
     _, y, _ = H.conv_nn(xg, wp, D, 1, 1, widx=widx)
     assert rel_l2(y, ref) < FWD_TOL
-    wpt = H.pack_weights(Wg, S, C, D, 1, C * D, D, 1, 0)
+    wpt = H.pack_weights(Wg, S, C, D, 1, C * D, D, 1, 0, shape=(T, 1))
     _, dx, _ = H.conv_nn(dyg, wpt, C, 1, 1, widx=widx)
     assert rel_l2(dx, x.grad) < GRAD_TOL
     order, seg = H.group_by_index(subj.cuda(), S)
@@ -270,7 +270,7 @@ def test_clip_kernels(H, B, Bc, Fd, T):
     assert rel_l2(scores, scores_ref) < FWD_TOL
     assert rel_l2(probs, torch.softmax(scores_ref, 1)) < 1e-5
     assert abs(float(loss) - float(loss_ref)) < 1e-5
-    wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0)
+    wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, shape=(K, 1))
     _, dest, _ = H.conv_nn(cg.view(1, Bc, K), wp, B, 1, 1)
     assert rel_l2(dest.view(B, Fd, T), est.grad) < GRAD_TOL
 
