@@ -71,6 +71,36 @@ __device__ __forceinline__ double bm_wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// max |x| of a tensor, published by the kernel that produces it (consumed as the f16x2 scale of the next
+// contraction, conv_nn_h2w.hip): every workgroup folds its maximum through LDS and stores it to ws[workgroup id]
+// (plain store: no atomics, nothing to zero beforehand); a one-workgroup kernel (bm_amax_finalize, core.hip)
+// then reduces the partial maxima into the amax slot.  A slot is BM_AMAX_SHARDS floats whose maximum is the
+// answer (the consumers take bm_amax_load); the workspace holds BM_AMAX_WS floats, the upper bound of every
+// producer's grid, and can be shared by all producers of one stream.
+#define BM_AMAX_SHARDS 8
+#define BM_AMAX_WS 16384
+__device__ __forceinline__ float bm_wave_max(float v);
+__device__ __forceinline__ void bm_publish_amax(float m, float* ws, float* sh /* >= blockDim / 64 floats of LDS */) {
+    if (!ws) return;                                   // kernel argument: uniform
+    m = bm_wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        float v = sh[0];
+        for (int w = 1; w < nw; ++w) v = fmaxf(v, sh[w]);
+        ws[blockIdx.y * gridDim.x + blockIdx.x] = v;
+    }
+}
+__device__ __forceinline__ float bm_amax_load(const float* slot) {
+    float m = slot[0];
+#pragma unroll
+    for (int i = 1; i < BM_AMAX_SHARDS; ++i) m = fmaxf(m, slot[i]);
+    return m;
+}
+// host: reduce n partial maxima (ws) into the slot `out`; no-op when out is null
+int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream);
+
 __device__ __forceinline__ float bm_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -38,41 +38,69 @@ extern "C" int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_n
     return bm_check_launch("clip_inv_norms");
 }
 
-// One wavefront per estimate row b:
-//   scores[b][o] = inv_norm[o] * sum_split part[split][b][o]
+// One workgroup (4 wavefronts) per estimate row b:
+//   scores[b][o] = inv_norm[o] * sum_split part[split][b][o]      (fixed split order: deterministic)
 //   loss_row[b]  = logsumexp_o(scores[b]) - scores[b][tgt], tgt = b + target_offset
 //                  (F.cross_entropy, target = arange(B); the offset lets a rank point at its own
 //                   block of whole-node gathered candidates without re-ordering them)
 //   probs[b][o]  = softmax_o(scores[b])                            (get_probabilities, losses.py:97-102)
 //   dscaled[b][o]= (probs - [o==b]) / B * inv_norm[o]              (d loss / d(est.cand[o]) )
-__global__ void clip_ce_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ inv_norm,
-                               float* __restrict__ scores, float* __restrict__ probs,
-                               float* __restrict__ dscaled, float* __restrict__ loss_row, int B, int Bc,
-                               int target_offset) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= B) return;
+// The fold of the split-K partial tiles is the expensive part (nsplit * B * B' * 4 bytes): consecutive threads
+// read consecutive columns of one partial row (coalesced), eight splits in flight per thread.
+__device__ __forceinline__ float clip_block_max(float v, float* sh) {
+    v = bm_wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ float clip_block_sum(float v, float* sh) {
+    v = bm_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return v;
+}
+
+__global__ __launch_bounds__(256) void clip_ce_kernel(const float* __restrict__ part, int nsplit,
+                                                      const float* __restrict__ inv_norm, float* __restrict__ scores,
+                                                      float* __restrict__ probs, float* __restrict__ dscaled,
+                                                      float* __restrict__ loss_row, int B, int Bc, int target_offset) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
     const long per = (long)B * Bc;
     const int tgt = b + target_offset;
+    float* srow = scores + (long)b * Bc;
     float mx = -INFINITY;
-    for (int o = lane; o < Bc; o += 64) {
+    for (int o = threadIdx.x; o < Bc; o += 256) {
+        const float* p = part + (long)b * Bc + o;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(long)k * per + (long)b * Bc + o];
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * per];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; ++k) s += p[(long)k * per];
         s *= inv_norm[o];
-        scores[(long)b * Bc + o] = s;
+        srow[o] = s;
         mx = fmaxf(mx, s);
     }
-    mx = bm_wave_max(mx);
+    mx = clip_block_max(mx, sh);
     float sum = 0.f;
-    for (int o = lane; o < Bc; o += 64) sum += expf(scores[(long)b * Bc + o] - mx);
-    sum = bm_wave_sum(sum);
+    for (int o = threadIdx.x; o < Bc; o += 256) sum += expf(srow[o] - mx);      // own writes: same thread, same o
+    sum = clip_block_sum(sum, sh);
     const float lse = mx + logf(sum);
     const float inv = 1.f / sum;
-    for (int o = lane; o < Bc; o += 64) {
-        const float s = scores[(long)b * Bc + o];
-        const float p = expf(s - mx) * inv;
-        if (probs) probs[(long)b * Bc + o] = p;
-        if (dscaled) dscaled[(long)b * Bc + o] = (p - (o == tgt ? 1.f : 0.f)) / (float)B * inv_norm[o];
+    for (int o = threadIdx.x; o < Bc; o += 256) {
+        const float s = srow[o];
+        const float pr = expf(s - mx) * inv;
+        if (probs) probs[(long)b * Bc + o] = pr;
+        if (dscaled) dscaled[(long)b * Bc + o] = (pr - (o == tgt ? 1.f : 0.f)) / (float)B * inv_norm[o];
         if (o == tgt && loss_row) loss_row[b] = lse - s;
     }
 }
@@ -96,7 +124,7 @@ extern "C" int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, 
     BM_REQUIRE(!loss || loss_row, "clip_ce: loss needs loss_row scratch");
     if (B == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(clip_ce_kernel, dim3((B + 3) / 4), dim3(256), 0, s, part, nsplit, inv_norm, scores,
+    hipLaunchKernelGGL(clip_ce_kernel, dim3(B), dim3(256), 0, s, part, nsplit, inv_norm, scores,
                        probs, dscaled, loss_row, B, Bc, target_offset);
     if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, loss_row, B, loss);
     return bm_check_launch("clip_ce");

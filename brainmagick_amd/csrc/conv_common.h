@@ -40,7 +40,8 @@ __device__ __forceinline__ void conv_ep_stage_params(const ConvNNArgs& a, float*
 // batch of independent loads before anything is stored.
 template <bool FULL>
 __device__ __forceinline__ void conv_ep_block_stores(const ConvNNArgs& a, const float* ep, int BM, int b,
-                                                     int m0, int rl0, int col, const float (&v)[16]) {
+                                                     int m0, int rl0, int col, const float (&v)[16],
+                                                     float* amx = nullptr) {
     const int row0 = m0 + rl0;
     const int base = row0 * a.T + col;
     float rv[16];
@@ -69,18 +70,22 @@ __device__ __forceinline__ void conv_ep_block_stores(const ConvNNArgs& a, const 
             float z = v[r] * ep[BM + rl] + ep[2 * BM + rl];
             z = bm_act(z, a.act, a.leak);
             if (a.res) z += rv[r];
-            if (FULL || row0 + dr < a.M) yo[base + dr * a.T] = z;
+            if (FULL || row0 + dr < a.M) {
+                yo[base + dr * a.T] = z;
+                if (amx) *amx = fmaxf(*amx, fabsf(z));      // max |y_out| for the f16x2 scale of the consumer
+            }
         }
     }
 }
 
 __device__ __forceinline__ void conv_ep_store_block(const ConvNNArgs& a, const f32x16& c, const float* ep,
-                                                    int BM, int b, int m0, int rl0, int col, float (&v)[16]) {
+                                                    int BM, int b, int m0, int rl0, int col, float (&v)[16],
+                                                    float* amx = nullptr) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = c[r] + ep[rl0 + (r & 3) + 8 * (r >> 2)];
     if (col < a.T) {
-        if (m0 + BM <= a.M) conv_ep_block_stores<true>(a, ep, BM, b, m0, rl0, col, v);
-        else conv_ep_block_stores<false>(a, ep, BM, b, m0, rl0, col, v);
+        if (m0 + BM <= a.M) conv_ep_block_stores<true>(a, ep, BM, b, m0, rl0, col, v, amx);
+        else conv_ep_block_stores<false>(a, ep, BM, b, m0, rl0, col, v, amx);
     }
 }
 

@@ -34,8 +34,9 @@ typedef int i32x4h __attribute__((ext_vector_type(4)));
 
 struct ConvH2Args {
     ConvNNArgs c;
-    const float* x_amax;      // [1] largest |x| of the input tensor (upper bounds are fine), device memory
+    const float* x_amax;      // [BM_AMAX_SHARDS] shards whose maximum bounds |x| of the input tensor, device memory
     const float* wscale;      // [G][Mpad] inverse row scales written by bm_pack_weights_h2
+    float* y_amax_ws;         // [>= grid] or null: per-workgroup max |y_out| (bm_publish_amax), folded by bm_amax_finalize
 };
 
 // Power-of-two scale s with amax * s in [2^14, 2^15), and its exact inverse.  amax == 0 / subnormal / inf /
@@ -81,37 +82,57 @@ struct H2Simple {
     float* yb;
     const float* rb;
     int rowu, li, T;
+    int row0, M;              // first row of this lane (rowu + 4 h), rows of the layer
     float bia[MW][16];
 };
 
-template <int MW, int NT, int MT>
-__device__ __forceinline__ void h2_simple_col(const H2Simple<MW>& e, f32x16 (&acc)[MW][3]) {
+template <int MW, int NT, int MT, bool FULL>
+__device__ __forceinline__ float h2_simple_col(const H2Simple<MW>& e, f32x16 (&acc)[MW][3], float amx) {
     if constexpr (MT < MW) {
+        // row of element r of this lane: e.row0 + MT * 32 + (r & 3) + 8 * (r >> 2); FULL: the tile lies inside M
         float rv[16];
         if (e.rb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                rv[r] = e.rb[(long)(e.rowu + MT * 32 + (r & 3) + 8 * (r >> 2)) * e.T + e.li + NT * 32];
+            for (int r = 0; r < 16; ++r) {
+                const int dr = MT * 32 + (r & 3) + 8 * (r >> 2);
+                rv[r] = (FULL || e.row0 + dr < e.M) ? e.rb[(long)(e.rowu + dr) * e.T + e.li + NT * 32] : 0.f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            const int dr = MT * 32 + (r & 3) + 8 * (r >> 2);
             float v = acc[MT][NT][r] + e.bia[MT][r];
             if (e.rb) v += rv[r];
-            e.yb[(long)(e.rowu + MT * 32 + (r & 3) + 8 * (r >> 2)) * e.T + e.li + NT * 32] = v;
+            if (FULL || e.row0 + dr < e.M) {
+                amx = fmaxf(amx, fabsf(v));
+                e.yb[(long)(e.rowu + dr) * e.T + e.li + NT * 32] = v;
+            }
         }
-        h2_simple_col<MW, NT, MT + 1>(e, acc);
+        return h2_simple_col<MW, NT, MT + 1, FULL>(e, acc, amx);
     }
+    return amx;
+}
+
+template <int MW, bool FULL>
+__device__ __forceinline__ float h2_simple_tile(const H2Simple<MW>& e, f32x16 (&acc)[MW][3], int col0, int T) {
+    float amx = 0.f;
+    if (col0 < T) amx = h2_simple_col<MW, 0, 0, FULL>(e, acc, amx);
+    if (col0 + 32 < T) amx = h2_simple_col<MW, 1, 0, FULL>(e, acc, amx);
+    if (col0 + 64 < T) amx = h2_simple_col<MW, 2, 0, FULL>(e, acc, amx);
+    return amx;
 }
 
 template <int MW, int I>
-__device__ __forceinline__ void h2_general_blocks(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* ep, int b,
-                                                  int m0, int rl_base, int col_base) {
+__device__ __forceinline__ float h2_general_blocks(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* ep, int b,
+                                                   int m0, int rl_base, int col_base, float amx) {
     if constexpr (I < MW * 3) {
         constexpr int MT = I / 3, NT = I % 3;
         float v[16];
-        conv_ep_store_block(a, acc[MT][NT], ep, 64 * MW, b, m0, rl_base + MT * 32, col_base + NT * 32, v);
-        h2_general_blocks<MW, I + 1>(a, acc, ep, b, m0, rl_base, col_base);
+        float m = 0.f;
+        conv_ep_store_block(a, acc[MT][NT], ep, 64 * MW, b, m0, rl_base + MT * 32, col_base + NT * 32, v, &m);
+        return h2_general_blocks<MW, I + 1>(a, acc, ep, b, m0, rl_base, col_base, fmaxf(amx, m));
     }
+    return amx;
 }
 
 template <int N, int MW>
@@ -163,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     // packed weights in 16-byte slots: [g][chunk32][tap][plane][4][Mpad]
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (long)g * nchunk32 * KS * 8 * a.Mpad + m0 + lane;
     float sx, sx_inv;
-    h2_scale_from_amax(*args.x_amax, sx, sx_inv);
+    h2_scale_from_amax(bm_amax_load(args.x_amax), sx, sx_inv);
 
     // input window of this segment through a bounds-checked buffer descriptor: channels past Cin read 0
     const unsigned long long xaddr = (unsigned long long)(a.x + (long)b * a.x_bstride);
@@ -334,11 +355,11 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
                 for (int nt = 0; nt < NW; ++nt) acc[mt][nt][r] *= f;
             }
     }
-    // Common case (every wide launch of the training step): one output tensor, no affine / activation, tile
-    // fully inside M.  Row addresses are wave-uniform bases + one per-lane offset + an immediate per column
-    // block, the row biases are read once: ~3 VALU issue slots per stored element instead of ~10.
-    const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE &&
-                        m0 + HBM <= a.M;
+    // Common case (every wide launch of the training step): one output tensor, no affine / activation.  Row
+    // addresses are wave-uniform bases + one per-lane offset + an immediate per column block, the row biases are
+    // read once: ~3 VALU issue slots per stored element instead of ~10.  Tiles that straddle M (270-channel
+    // layers in 320-row tiles) take the same path with a row predicate.
+    const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE;
     if (simple) {
         H2Simple<MW> e;
         e.yb = (a.y_pre ? a.y_pre : a.y_out) + (long)b * a.y_bstride;
@@ -346,17 +367,21 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
         e.rowu = m0 + wm * (MW * 32);                       // wave-uniform first row
         e.li = 4 * h * a.T + n0 + wn * (NW * 32) + nl;      // per-lane element offset inside a row block
         e.T = a.T;
+        e.row0 = e.rowu + 4 * h;
+        e.M = a.M;
         const float* epl = ep + wm * (MW * 32) + 4 * h;
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) e.bia[mt][r] = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
         const int col0 = n0 + wn * (NW * 32) + nl;
-        if (col0 < a.T) h2_simple_col<MW, 0, 0>(e, acc);
-        if (col0 + 32 < a.T) h2_simple_col<MW, 1, 0>(e, acc);
-        if (col0 + 64 < a.T) h2_simple_col<MW, 2, 0>(e, acc);
+        const float amx = m0 + HBM <= a.M ? h2_simple_tile<MW, true>(e, acc, col0, a.T)
+                                          : h2_simple_tile<MW, false>(e, acc, col0, a.T);
+        if (a.y_out) bm_publish_amax(amx, args.y_amax_ws, smem + 4 * HBM);
     } else {
-        h2_general_blocks<MW, 0>(a, acc, ep, b, m0, wm * (MW * 32) + 4 * h, n0 + wn * (NW * 32) + nl);
+        const float amx = h2_general_blocks<MW, 0>(a, acc, ep, b, m0, wm * (MW * 32) + 4 * h,
+                                                   n0 + wn * (NW * 32) + nl, 0.f);
+        bm_publish_amax(amx, args.y_amax_ws, smem + 4 * HBM);
     }
 }
 
@@ -471,49 +496,39 @@ extern "C" int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int
     return bm_check_launch("pack_weights_h2");
 }
 
-// out[0] = max |x[i]|  (bit pattern of a non-negative float orders like an unsigned integer; NaN sorts above
-// inf, so a non-finite input yields a non-finite maximum).  256 workgroups of 1024 threads, one atomic each.
-__global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
-    __shared__ unsigned red[16];
-    unsigned mx = 0u;
+// max |x[i]| as <= 256 per-workgroup partial maxima (ws) folded by bm_amax_finalize into the slot `out`
+// (BM_AMAX_SHARDS floats whose maximum is the answer).  A non-finite input yields a non-finite or NaN-free
+// maximum of the finite part; the non-finite values themselves propagate through the consumer's split.
+__global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x, long n, float* __restrict__ ws) {
+    __shared__ float sh[16];
+    float mx = 0.f;
     const long n4 = n >> 2;
-    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const uint4 v = x4[i];
-        mx = max(max(mx, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+        const float4 v = x4[i];
+        mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     if (blockIdx.x == 0)
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) mx = max(mx, __float_as_uint(x[i]) & 0x7fffffffu);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        mx = red[threadIdx.x];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-        if (threadIdx.x == 0) atomicMax(out, mx);
-    }
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, fabsf(x[i]));
+    bm_publish_amax(mx, ws, sh);
 }
 
-extern "C" int bm_amax(const float* x, long n, float* out, void* stream) {
-    BM_REQUIRE(x && out && n >= 0, "amax: bad arguments");
+extern "C" int bm_amax(const float* x, long n, float* out, float* ws, void* stream) {
+    BM_REQUIRE(x && out && ws && n >= 0, "amax: bad arguments");
     BM_REQUIRE(((uintptr_t)x & 15) == 0, "amax: x must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, 4, s);
-    if (e != hipSuccess) return bm_set_error((int)e, "amax: hipMemsetAsync: %s", hipGetErrorString(e));
-    if (n == 0) return BM_OK;
     long blocks = (n / 4 + 1023) / 1024;
     blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, x, n, reinterpret_cast<unsigned*>(out));
-    return bm_check_launch("amax");
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, x, n, ws);
+    if (int rc = bm_check_launch("amax")) return rc;
+    return bm_amax_finalize(ws, (int)blocks, out, s);
 }
 
 template <int KS, int MW>
-static int launch_conv_nn_h2w(ConvH2Args args, hipStream_t stream) {
+static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t stream) {
     constexpr int HBM = 64 * MW;
     size_t lds = (size_t)(3 * 2 * 2 * HBM + 2 * HXSLAB) * 16;
-    const size_t lds_ep = (size_t)4 * HBM * sizeof(float);
+    const size_t lds_ep = (size_t)(4 * HBM + 4) * sizeof(float);
     if (lds < lds_ep) lds = lds_ep;
     static bool attr_set = false;
     if (!attr_set) {
@@ -526,18 +541,26 @@ static int launch_conv_nn_h2w(ConvH2Args args, hipStream_t stream) {
     args.c.ntiles_m = args.c.Mpad / HBM;
     const long nblocks = (long)args.c.B * args.c.ntiles_n * args.c.ntiles_m;
     if (nblocks <= 0) return BM_OK;
+    const bool publish = y_amax_out && args.y_amax_ws && nblocks <= BM_AMAX_WS;
+    float* ws = args.y_amax_ws;
+    if (!publish) args.y_amax_ws = nullptr;
     hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
-    return bm_check_launch("conv_nn_h2w");
+    if (int rc = bm_check_launch("conv_nn_h2w")) return rc;
+    if (publish) return bm_amax_finalize(ws, (int)nblocks, y_amax_out, stream);
+    if (y_amax_out && ws)           // grid larger than the workspace: a plain pass over the output instead
+        return bm_amax(args.c.y_out, (long)args.c.B * args.c.M * args.c.T, y_amax_out, ws, stream);
+    return BM_OK;
 }
 
 // Same contract as bm_conv1d_nn plus `x_amax` (device pointer to max |x|, e.g. from bm_amax; any upper bound
-// within a factor 2 of the fp16 range works); weights packed by bm_pack_weights_h2; only shapes for which
+// within a factor 2 of the fp16 range works) and `y_amax_out` (nullable amax slot: receives max |y_out| for the
+// contraction that consumes the output; `amax_ws` = BM_AMAX_WS floats of scratch shared by all producers of the stream); weights packed by bm_pack_weights_h2; only shapes for which
 // bm_conv_h2_covers() is 1.
 extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked,
                                const int* widx, const float* bias, const float* ep_scale, const float* ep_shift,
                                const float* res, long res_bstride, float* y_pre, float* y_out, long y_bstride,
                                float* stats, int B, int Cin, int M, int T, int KS, int dil, int act, float leak,
-                               int G, void* stream) {
+                               int G, float* y_amax_out, float* amax_ws, void* stream) {
     BM_REQUIRE(x && wpacked && x_amax, "conv1d_nn_h2: null x / w / x_amax");
     BM_REQUIRE(y_pre || y_out, "conv1d_nn_h2: no output");
     BM_REQUIRE(!stats, "conv1d_nn_h2: per-tile statistics are not produced by this kernel");
@@ -556,10 +579,13 @@ extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_am
     a.nchunk = cdiv(Cin, 32);
     const long f16_elems = (long)G * a.nchunk * KS * 2 * 4 * a.Mpad * 8;
     args.x_amax = x_amax;
+    BM_REQUIRE(!y_amax_out || amax_ws, "conv1d_nn_h2: y_amax_out needs the amax workspace");
+    if (!y_out) y_amax_out = nullptr;
+    args.y_amax_ws = y_amax_out ? amax_ws : nullptr;
     args.wscale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpacked) + f16_elems * 2);
     hipStream_t s = (hipStream_t)stream;
 #define H2_DISPATCH(MW_)                                                                 \
-    return KS == 1 ? launch_conv_nn_h2w<1, MW_>(args, s) : launch_conv_nn_h2w<3, MW_>(args, s);
+    return KS == 1 ? launch_conv_nn_h2w<1, MW_>(args, y_amax_out, s) : launch_conv_nn_h2w<3, MW_>(args, y_amax_out, s);
     switch (mw) {
         case 5: H2_DISPATCH(5)
         case 4: H2_DISPATCH(4)

@@ -28,3 +28,27 @@ extern "C" int bm_device_count(void) {
     if (e != hipSuccess) { bm_set_error((int)e, "hipGetDeviceCount: %s", hipGetErrorString(e)); return -1; }
     return n;
 }
+
+// out[0] = max_i ws[i] (NaN-ignoring fmaxf; partial maxima are >= 0), out[1 .. BM_AMAX_SHARDS) = 0
+__global__ __launch_bounds__(1024) void amax_finalize_kernel(const float* __restrict__ ws, int n, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, ws[i]);
+    m = bm_wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < BM_AMAX_SHARDS) {
+        float v = 0.f;
+        if (threadIdx.x == 0)
+            for (int w = 0; w < 16; ++w) v = fmaxf(v, sh[w]);
+        out[threadIdx.x] = v;
+    }
+}
+
+int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream) {
+    if (!out) return BM_OK;
+    hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, stream, ws, n, out);
+    return bm_check_launch("amax_finalize");
+}
+
+extern "C" int bm_amax_ws_elems(void) { return BM_AMAX_WS; }

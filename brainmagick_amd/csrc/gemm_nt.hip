@@ -279,6 +279,17 @@ extern "C" int bm_gemm_nt_suggest_splits(int M, int Cn, int KS, int S, int T, in
     return (int)want;
 }
 
+// Split count of the ClipLoss score contraction (M x Cn outputs, K = S * T long): one workgroup per CU -- more
+// splits only add partial-tile traffic (nsplit * M * Cn * 4 bytes written here, read again by bm_clip_ce).
+extern "C" int bm_clip_suggest_splits(int M, int Cn, int S, int T) {
+    const int tiles = cdiv(M, prefer_big(M) ? 128 : 64) * cdiv(Cn, prefer_big(Cn) ? 128 : 64);
+    const long chunks = (long)S * cdiv(T, BKT);
+    long want = (256 + tiles - 1) / tiles;
+    if (want > chunks / 8) want = chunks / 8;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
 extern "C" int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x,
                           long x_sstride, long x_rstride, const int* order, const int* seg,
                           float* part, int S, int G, int M, int Cn, int T, int KS, int dil,

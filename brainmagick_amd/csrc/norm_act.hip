@@ -125,8 +125,10 @@ template <int VEC>
 __global__ void affine_act_res_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                       const float* __restrict__ shift, const float* __restrict__ res,
                                       float* __restrict__ out, long nvec, int C, int T, int act,
-                                      float leak) {
+                                      float leak, float* __restrict__ amax_ws) {
+    __shared__ float amax_sh[4];
     const int TV = T / VEC;
+    float amx = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec;
          e += (long)gridDim.x * blockDim.x) {
         const long row = e / TV;
@@ -140,29 +142,36 @@ __global__ void affine_act_res_kernel(const float* __restrict__ y, const float* 
             float z = bm_act(v.v[i] * sc + sh, act, leak);
             if (res) z += r.v[i];
             v.v[i] = z;
+            amx = fmaxf(amx, fabsf(z));
         }
         v.st(out + e * VEC);
     }
+    bm_publish_amax(amx, amax_ws, amax_sh);
 }
 
 extern "C" int bm_affine_act_res(const float* y, const float* scale, const float* shift,
                                  const float* res, float* out, int B, int C, int T, int act,
-                                 float leak, void* stream) {
+                                 float leak, float* amax_out, float* amax_ws, void* stream) {
     BM_REQUIRE(y && out, "affine_act_res: null pointer");
+    BM_REQUIRE(!amax_out || amax_ws, "affine_act_res: amax_out needs the amax workspace");
     const long n = (long)B * C * T;
     if (n == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
+    int nblk = 0;
     if (T % 4 == 0) {
         const long nvec = n / 4;
         const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
         hipLaunchKernelGGL(affine_act_res_kernel<4>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
-                           out, nvec, C, T, act, leak);
+                           out, nvec, C, T, act, leak, amax_out ? amax_ws : nullptr);
+        nblk = blocks;
     } else {
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
         hipLaunchKernelGGL(affine_act_res_kernel<1>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
-                           out, n, C, T, act, leak);
+                           out, n, C, T, act, leak, amax_out ? amax_ws : nullptr);
+        nblk = blocks;
     }
-    return bm_check_launch("affine_act_res");
+    if (int rc = bm_check_launch("affine_act_res")) return rc;
+    return bm_amax_finalize(amax_ws, nblk, amax_out, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,8 +223,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ partial, int bn_train, float* __restrict__ dy,
     double* __restrict__ dy_partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-    int C, int T, int act, float leak) {
+    int C, int T, int act, float leak, float* __restrict__ amax_ws) {
     __shared__ double sh[4];
+    __shared__ float amax_sh[4];
+    float amx = 0.f;
     const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
@@ -254,9 +265,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             else if (scale) g = sc * dz;
             o.v[i] = g;
             sdy += g;
+            amx = fmaxf(amx, fabsf(g));
         }
         o.st(dy + off);
     }
+    bm_publish_amax(amx, amax_ws, amax_sh);
     double acc[1] = {(double)sdy};
     block_sum<1>(acc, sh);
     if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc[0];
@@ -283,8 +296,10 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
                              const float* shift, const float* mean, const float* invstd,
                              int bn_train, float* dy, float* dgamma, float* dbeta, float* dbias,
                              void* workspace, long workspace_bytes, int B, int C, int T, int act,
-                             float leak, void* stream) {
+                             float leak, float* amax_out, float* amax_ws, void* stream) {
     BM_REQUIRE(dout && y && dy, "act_bn_bwd: null pointer");
+    BM_REQUIRE(!amax_out || amax_ws, "act_bn_bwd: amax_out needs the amax workspace");
+    BM_REQUIRE(!amax_out || (long)C * bm_bwd_nsplit(B) <= BM_AMAX_WS, "act_bn_bwd: too many channels for the amax workspace");
     BM_REQUIRE(!bn_train || (scale && shift && mean && invstd), "act_bn_bwd: train BN needs saved statistics");
     if ((long)B * C * T == 0) return BM_OK;
     const int nsplit = bm_bwd_nsplit(B);
@@ -301,18 +316,21 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
-                           invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak);
+                           invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
+                           amax_out ? amax_ws : nullptr);
     } else {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
-                           invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak);
+                           invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
+                           amax_out ? amax_ws : nullptr);
     }
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dy_partial,
                            dbias, C, nsplit);
-    return bm_check_launch("act_bn_bwd");
+    if (int rc = bm_check_launch("act_bn_bwd")) return rc;
+    return bm_amax_finalize(amax_ws, C * nsplit, amax_out, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,8 +427,10 @@ extern "C" int bm_channel_stats(const float* x, float* stats, int B, int C, int 
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ void glu_fwd_kernel(const float* __restrict__ u, float* __restrict__ out, long nvec, int H,
-                               int T) {
+                               int T, float* __restrict__ amax_ws) {
+    __shared__ float amax_sh[4];
     const int TV = T / VEC;
+    float amx = 0.f;
     const long per = (long)H * TV;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec;
          e += (long)gridDim.x * blockDim.x) {
@@ -420,33 +440,46 @@ __global__ void glu_fwd_kernel(const float* __restrict__ u, float* __restrict__ 
         const Pack<VEC> a = Pack<VEC>::ld(ua), g = Pack<VEC>::ld(ua + (long)H * T);
         Pack<VEC> o;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) o.v[i] = a.v[i] / (1.f + expf(-g.v[i]));
+        for (int i = 0; i < VEC; ++i) {
+            o.v[i] = a.v[i] / (1.f + expf(-g.v[i]));
+            amx = fmaxf(amx, fabsf(o.v[i]));
+        }
         o.st(out + e * VEC);
     }
+    bm_publish_amax(amx, amax_ws, amax_sh);
 }
 
-extern "C" int bm_glu_fwd(const float* u, float* out, int B, int H, int T, void* stream) {
+extern "C" int bm_glu_fwd(const float* u, float* out, int B, int H, int T, float* amax_out, float* amax_ws,
+                          void* stream) {
     BM_REQUIRE(u && out, "glu_fwd: null pointer");
+    BM_REQUIRE(!amax_out || amax_ws, "glu_fwd: amax_out needs the amax workspace");
     const long n = (long)B * H * T;
     if (n == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
+    int nblk = 0;
     if (T % 4 == 0) {
         const long nvec = n / 4;
         const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
-        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T);
+        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T, amax_out ? amax_ws : nullptr);
+        nblk = blocks;
     } else {
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
-        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T);
+        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T, amax_out ? amax_ws : nullptr);
+        nblk = blocks;
     }
-    return bm_check_launch("glu_fwd");
+    if (int rc = bm_check_launch("glu_fwd")) return rc;
+    return bm_amax_finalize(amax_ws, nblk, amax_out, s);
 }
 
 // du_a = dout * sig(g) ; du_g = dout * a * sig(g) * (1 - sig(g)); also per-channel sums (bias grad).
 template <int VEC>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ dout,
                                                       const float* __restrict__ u, float* __restrict__ du,
-                                                      double* __restrict__ partial, int B, int H, int T) {
+                                                      double* __restrict__ partial, int B, int H, int T,
+                                                      float* __restrict__ amax_ws) {
     __shared__ double sh[4 * 2];
+    __shared__ float amax_sh[4];
+    float amx = 0.f;
     const int hch = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
@@ -468,10 +501,12 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
             og.v[i] = d.v[i] * a.v[i] * sgm * (1.f - sgm);
             sa += oa.v[i];
             sg += og.v[i];
+            amx = fmaxf(amx, fmaxf(fabsf(oa.v[i]), fabsf(og.v[i])));
         }
         oa.st(du + offa);
         og.st(du + offg);
     }
+    bm_publish_amax(amx, amax_ws, amax_sh);
     double acc[2] = {(double)sa, (double)sg};
     block_sum<2>(acc, sh);
     if (threadIdx.x == 0 && partial) {
@@ -485,8 +520,10 @@ extern "C" long bm_glu_bwd_workspace_bytes(int B, int H) {
 }
 
 extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
-                          long workspace_bytes, int B, int H, int T, void* stream) {
+                          long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws, void* stream) {
     BM_REQUIRE(dout && u && du, "glu_bwd: null pointer");
+    BM_REQUIRE(!amax_out || amax_ws, "glu_bwd: amax_out needs the amax workspace");
+    BM_REQUIRE(!amax_out || (long)H * bm_bwd_nsplit(B) <= BM_AMAX_WS, "glu_bwd: too many channels for the amax workspace");
     if ((long)B * H * T == 0) return BM_OK;
     const int nsplit = bm_bwd_nsplit(B);
     if (workspace_bytes < bm_glu_bwd_workspace_bytes(B, H))
@@ -494,11 +531,14 @@ extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* d
     double* partial = (double*)workspace;
     hipStream_t s = (hipStream_t)stream;
     if (T % 4 == 0)
-        hipLaunchKernelGGL(glu_bwd_kernel<4>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T);
+        hipLaunchKernelGGL(glu_bwd_kernel<4>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T,
+                           amax_out ? amax_ws : nullptr);
     else
-        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T);
+        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T,
+                           amax_out ? amax_ws : nullptr);
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, s, partial,
                            dbias, 2 * H, nsplit);
-    return bm_check_launch("glu_bwd");
+    if (int rc = bm_check_launch("glu_bwd")) return rc;
+    return bm_amax_finalize(amax_ws, H * nsplit, amax_out, s);
 }

@@ -52,7 +52,13 @@ class Conv1dFn(torch.autograd.Function):
             M, Cin, KS = weight.shape
             wp = H.pack_conv_fwd(weight, (x.shape[2], dil))
         need_pre = act != H.ACT_NONE and (x.requires_grad or weight.requires_grad)
-        pre, out, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, act=act, leak=leak, want_pre=need_pre)
+        if need_pre:
+            # training: the pre-activation is saved anyway; the activation as a streaming pass over it is cheaper
+            # than the conv kernel's general epilogue (erf per accumulator element with the matrix cores idle)
+            pre, _, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False)
+            out = H.affine_act_res(pre, None, None, None, act, leak)
+        else:
+            pre, out, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, act=act, leak=leak)
         ctx.save_for_backward(x, weight, pre)
         ctx.cfg = (dil, act, leak, transposed_weight, KS, bias is not None)
         return out

@@ -110,21 +110,62 @@ def conv_mpad(M: int) -> int:
     return lib().bm_conv_mpad(M)
 
 
+AMAX_SHARDS = 8       # an amax slot is 8 floats (shards of the atomic maximum, see csrc/bm_common.h); max|x| = slot.max()
+amax_scans = 0        # number of stand-alone amax passes launched (producers that publish their own maximum need none)
+
+
 def amax(x: torch.Tensor) -> torch.Tensor:
-    """[1] fp32 tensor holding max |x| (device side, no sync).  Cached on the tensor object together with
+    """[AMAX_SHARDS] fp32 tensor whose maximum is max |x| (device side, no sync).  Cached on the tensor object together with
     its version counter, so a tensor consumed by several contractions (forward conv, weight gradient) is
     scanned once and an in-place modification invalidates the cache."""
     cached = getattr(x, "_bm_amax", None)
     if cached is not None and cached[0] == x._version and cached[1] == x.data_ptr():
         return cached[2]
     _req(x, "amax.x")
-    out = torch.empty(1, device=x.device, dtype=torch.float32)
-    check(lib().bm_amax(_p(x), x.numel(), _p(out), _stream()), "bm_amax")
+    global amax_scans
+    amax_scans += 1
+    out = torch.empty(AMAX_SHARDS, device=x.device, dtype=torch.float32)
+    check(lib().bm_amax(_p(x), x.numel(), _p(out), _p(_amax_ws(x.device)), _stream()), "bm_amax")
     try:
         x._bm_amax = (x._version, x.data_ptr(), out)
     except Exception:       # tensors that refuse attributes: just do not cache
         pass
     return out
+
+
+_NO_PUBLISH = _os.environ.get("BM_NO_AMAX_PUBLISH", "0") == "1"     # A/B switch: stand-alone amax passes instead
+_amax_pool: tp.Dict[torch.device, tp.List[tp.Any]] = {}
+_amax_workspaces: tp.Dict[tp.Any, torch.Tensor] = {}
+
+
+def _amax_ws(device) -> torch.Tensor:
+    """Scratch for the per-workgroup partial maxima: one buffer per (device, stream); kernels of one stream run in
+    order, so every producer of that stream can use the same buffer."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _amax_workspaces.get(key)
+    if ws is None:
+        ws = _amax_workspaces[key] = torch.empty(lib().bm_amax_ws_elems(), device=device, dtype=torch.float32)
+    return ws
+
+
+def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
+    """An [AMAX_SHARDS] fp32 slot for a producer kernel to publish max|t| into (f16x2 mode only; None otherwise).
+    Slots are carved out of pooled buffers, each slot is used once.  The slot is attached to the tensor like
+    `amax()` would, so the consuming contraction finds it without a pass over the tensor."""
+    if _compute_dtype != "f16x2" or _NO_PUBLISH:
+        return None
+    pool = _amax_pool.get(t.device)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _amax_pool[t.device] = [torch.empty(4096 * AMAX_SHARDS, device=t.device, dtype=torch.float32), 0]
+    slot = pool[0][pool[1]:pool[1] + AMAX_SHARDS]
+    pool[1] += AMAX_SHARDS
+    t._bm_amax = (t._version, t.data_ptr(), slot)
+    return slot
+
+
+def _slot_args(slot):
+    """(amax_out, amax_ws) arguments of a producer."""
+    return (_p(slot), _p(_amax_ws(slot.device)) if slot is not None else None)
 
 
 def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, sm: int, sc: int,
@@ -195,10 +236,11 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
               KS, dil, act, leak)
     if mode == "f16x2":
         x_amax = amax(x)
+        y_slot = _amax_slot(y_out) if y_out is not None else None
 
         def launch():
             check(lib().bm_conv1d_nn_h2(_p(x), Cin * T, _p(x_amax), _p(wpacked), *common, wpacked._bm_groups,
-                                        _stream()), "bm_conv1d_nn_h2")
+                                        *_slot_args(y_slot), _stream()), "bm_conv1d_nn_h2")
     else:
         fn = {"f32": lib().bm_conv1d_nn, "bf16": lib().bm_conv1d_nn_bf16,
               "f32x3": lib().bm_conv1d_nn_x3}[mode]
@@ -342,18 +384,29 @@ def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
     """Split-K partial tiles [nsplit][M][Cn] (KS=1, one group), consumed by clip_ce."""
     _req(a, "gemm_nt.a")
     _req(x, "gemm_nt.x")
+    # scores feed a softmax: exact fp32 or an fp32-accurate path, never plain bf16
+    mode = "f32" if _compute_dtype == "bf16" else _compute_dtype
+    if mode == "f16x2" and not lib().bm_gemm_nt_h2_covers(M, Cn, 1, S, T, 1, 1, 0):
+        mode = "f32x3"
     if nsplit is None:
-        nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, 1, S, T, 1)
+        nsplit = lib().bm_gemm_nt_h2_suggest_splits(M, Cn, 1, S, T) if mode == "f16x2" else \
+            lib().bm_clip_suggest_splits(M, Cn, S, T)
     part = torch.empty(nsplit, M, Cn, device=a.device, dtype=torch.float32)
-    # scores feed a softmax: exact fp32 or the fp32-accurate x3 path, never plain bf16
-    x3 = _compute_dtype in ("f32x3", "f16x2")
-    fn = lib().bm_gemm_nt_x3 if x3 else lib().bm_gemm_nt
+    if mode == "f16x2":
+        a_amax, x_amax = amax(a), amax(x)
 
-    def launch():
-        check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1], None, None, _p(part),
-                 S, 1, M, Cn, T, 1, 1, nsplit, _stream()), "bm_gemm_nt")
+        def launch():
+            check(lib().bm_gemm_nt_h2(_p(a), a_strides[0], a_strides[1], _p(a_amax), _p(x), x_strides[0],
+                                      x_strides[1], _p(x_amax), _p(part), S, M, Cn, T, 1, 1, nsplit, _stream()),
+                  "bm_gemm_nt_h2")
+    else:
+        fn = lib().bm_gemm_nt_x3 if mode == "f32x3" else lib().bm_gemm_nt
+
+        def launch():
+            check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1], None, None, _p(part),
+                     S, 1, M, Cn, T, 1, 1, nsplit, _stream()), "bm_gemm_nt")
     if _timer is not None:
-        _timer.launch("clip_scores:gemm_nt" + ("_x3" if x3 else ""),
+        _timer.launch("clip_scores:gemm_nt" + {"f32": "", "f32x3": "_x3", "f16x2": "_h2w"}[mode],
                       2.0 * S * T * M * Cn, launch)
     else:
         launch()
@@ -401,8 +454,8 @@ def affine_act_res(y, scale, shift, res, act: int, leak: float = 0.):
     B, C, T = y.shape
     out = torch.empty_like(y)
     check(lib().bm_affine_act_res(_p(y), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")),
-                                  _p(_opt(res, "res")), _p(out), B, C, T, act, leak, _stream()),
-          "bm_affine_act_res")
+                                  _p(_opt(res, "res")), _p(out), B, C, T, act, leak, *_slot_args(_amax_slot(out)),
+                                  _stream()), "bm_affine_act_res")
     return out
 
 
@@ -421,7 +474,7 @@ def act_bn_bwd(dout, y, scale, shift, mean, invstd, bn_train: bool, act: int, le
     check(lib().bm_act_bn_bwd(_p(dout), _p(y), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")),
                               _p(_opt(mean, "mean")), _p(_opt(invstd, "invstd")), int(bn_train),
                               _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), nbytes, B, C, T, act,
-                              leak, _stream()), "bm_act_bn_bwd")
+                              leak, *_slot_args(_amax_slot(dy)), _stream()), "bm_act_bn_bwd")
     return dy, dgamma, dbeta, dbias
 
 
@@ -449,7 +502,7 @@ def glu_fwd(u: torch.Tensor) -> torch.Tensor:
     _req(u, "glu_fwd.u")
     B, C2, T = u.shape
     out = torch.empty(B, C2 // 2, T, device=u.device, dtype=torch.float32)
-    check(lib().bm_glu_fwd(_p(u), _p(out), B, C2 // 2, T, _stream()), "bm_glu_fwd")
+    check(lib().bm_glu_fwd(_p(u), _p(out), B, C2 // 2, T, *_slot_args(_amax_slot(out)), _stream()), "bm_glu_fwd")
     return out
 
 
@@ -462,8 +515,8 @@ def glu_bwd(dout: torch.Tensor, u: torch.Tensor, want_dbias: bool = True):
     dbias = torch.empty(C2, device=u.device, dtype=torch.float32) if want_dbias else None
     nbytes = lib().bm_glu_bwd_workspace_bytes(B, H)
     ws = torch.empty(nbytes, device=u.device, dtype=torch.uint8)
-    check(lib().bm_glu_bwd(_p(dout), _p(u), _p(du), _p(dbias), _p(ws), nbytes, B, H, T, _stream()),
-          "bm_glu_bwd")
+    check(lib().bm_glu_bwd(_p(dout), _p(u), _p(du), _p(dbias), _p(ws), nbytes, B, H, T,
+                           *_slot_args(_amax_slot(du)), _stream()), "bm_glu_bwd")
     return du, dbias
 
 

@@ -102,7 +102,8 @@ int bm_gemm_nt_bf16(const float* a, long a_sstride, long a_rstride, const float*
  * is scaled by a power of two (per tensor for activations, per output row for weights) and split into two f16
  * planes; three partial products per MFMA block, fp32 accumulate, exact inverse scaling in the epilogue.  Half
  * the matrix-core work of "f32x3" at the same parity tolerances.  Same conv contract as bm_conv1d_nn plus
- * `x_amax` (device pointer to max|x| of the input tensor, e.g. from bm_amax) and G (weight groups packed).
+ * `x_amax` (device pointer to an amax slot of the input tensor: 8 floats whose maximum is max|x|, from bm_amax or
+ * published by the producing kernel) and G (weight groups packed).
  * Shapes bm_conv_h2_covers() rejects go through bm_conv1d_nn_x3 (also fp32-accurate). */
 int bm_conv_h2_mw_for(int M);
 int bm_conv_h2_mpad(int M);
@@ -110,11 +111,15 @@ int bm_conv_h2_covers(int Cin, int M, int T, int KS, int dil);
 long bm_packed_weight_bytes_h2(int G, int M, int Cin, int KS);
 int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm, long sc,
                        long sj, int flip, const float* alpha_ptr, void* stream);
-int bm_amax(const float* x, long n, float* out, void* stream);
+/* amax slots and workspace: a slot is 8 floats whose maximum is max|x|; `amax_ws` is 16384 floats of scratch that
+ * the producers of one stream may share (per-workgroup partial maxima, folded by a one-workgroup kernel). */
+int bm_amax_ws_elems(void);
+int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
 int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked, const int* widx,
                     const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B, int Cin,
-                    int M, int T, int KS, int dil, int act, float leak, int G, void* stream);
+                    int M, int T, int KS, int dil, int act, float leak, int G, float* y_amax_out, float* amax_ws,
+                    void* stream);
 
 /* f16x2 weight gradients (gemm_nt_h2w.hip): part[split][m][c*KS + j] over S consecutive segments, one group,
  * KS in {1, 3}; a_amax / x_amax = device pointers to max|a| / max|x| (bm_amax).  Shapes bm_gemm_nt_h2_covers()
@@ -130,6 +135,7 @@ int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, const float* a
  * Replaces aten::convolution_backward (weight part), the weight-grad einsums of SubjectLayers /
  * ChannelMerger, torch.einsum("bct,oct,o->bo") (losses.py:94) and einsum("bcd,bod->boc") (common.py:355). */
 int bm_gemm_nt_suggest_splits(int M, int Cn, int KS, int S, int T, int G);
+int bm_clip_suggest_splits(int M, int Cn, int S, int T);
 int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                int Cn, int T, int KS, int dil, int nsplit, void* stream);
@@ -142,24 +148,27 @@ int bm_bn_finalize(const float* stats, int ntiles, int C, long count, const floa
 int bm_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* mean, float* invstd, float* scale,
                       float* shift, void* stream);
+/* `amax_out` (nullable amax slot) + `amax_ws` on the elementwise producers: the slot receives max|output|, the
+ * f16x2 scale of the contraction that consumes the tensor -- saves a separate bm_amax pass over it. */
 int bm_affine_act_res(const float* y, const float* scale, const float* shift, const float* res,
-                      float* out, int B, int C, int T, int act, float leak, void* stream);
+                      float* out, int B, int C, int T, int act, float leak, float* amax_out, float* amax_ws,
+                      void* stream);
 int bm_bwd_nsplit(int B);
 long bm_act_bn_bwd_workspace_bytes(int B, int C);
 int bm_act_bn_bwd(const float* dout, const float* y, const float* scale, const float* shift,
                   const float* mean, const float* invstd, int bn_train, float* dy, float* dgamma,
                   float* dbeta, float* dbias, void* workspace, long workspace_bytes, int B, int C,
-                  int T, int act, float leak, void* stream);
+                  int T, int act, float leak, float* amax_out, float* amax_ws, void* stream);
 long bm_channel_sum_workspace_bytes(int B, int C);
 int bm_channel_sum(const float* x, long bstride, float* out, void* workspace, long workspace_bytes,
                    int B, int C, int T, void* stream);
 /* one-pass per-channel (sum, sumsq) partials [nsplit][C][2] of a conv output, folded by bm_bn_finalize */
 int bm_channel_stats_splits(int B);
 int bm_channel_stats(const float* x, float* stats, int B, int C, int T, void* stream);
-int bm_glu_fwd(const float* u, float* out, int B, int H, int T, void* stream);
+int bm_glu_fwd(const float* u, float* out, int B, int H, int T, float* amax_out, float* amax_ws, void* stream);
 long bm_glu_bwd_workspace_bytes(int B, int H);
 int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
-               long workspace_bytes, int B, int H, int T, void* stream);
+               long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws, void* stream);
 
 /* ---- ScaleReject front end (scale.hip)  bm/norm.py:86-87,255-261,325-341; bm/solver.py:245-246 ----
  * out = clamp((x - center[group[b]][c]) / scale[group[b]][c]); maxabs[b] = max|out[b]| (zero-init). */

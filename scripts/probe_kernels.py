@@ -10,6 +10,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import brainmagick_amd  # noqa: E402
 from brainmagick_amd import hip_ops as H  # noqa: E402
 
+import os
+WANT_PRE = os.environ.get("PROBE_OUT", "0") != "1"
 what = sys.argv[1] if len(sys.argv) > 1 else "conv"
 modes = sys.argv[2:] or ["f32x3", "f16x2"]
 B, T = 256, 360
@@ -42,7 +44,7 @@ if what == "conv":
                 brainmagick_amd.set_compute_dtype(mode)
                 wp = H.pack_conv_fwd(w, (T, dil))
                 H.amax(x)
-                t = timeit(lambda: H.conv_nn(x, wp, M, KS, dil, want_pre=True, want_out=False))
+                t = timeit(lambda: H.conv_nn(x, wp, M, KS, dil, want_pre=WANT_PRE, want_out=not WANT_PRE))
                 res.setdefault(mode, []).append(t)
         fl = 2.0 * B * T * M * Cin * KS
         print(f"conv Cin={Cin} M={M} KS={KS} d={dil}: " + "  ".join(
