@@ -282,7 +282,6 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     STORE_X(0)
     if (KS == 1) LOAD_X(1)          // 1x1 convs: the window of chunk c + 2 is requested in stage c (see below)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    FRAGS_EARLY(0, 0, 0)
 
     // Stage s = (16-channel chunk c16, tap j), A buffer s % 3, X buffer c16 & 1.  VMEM queue order inside a
     // stage: [input window of chunk c16 + 1, 16 loads, if j == 0], slab s + 2 (MW DMA copies).  Before the
@@ -292,8 +291,14 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     // slab; it is split in stage c, and only then is the window of chunk c + 2 requested into the same
     // registers - queue order per stage: slab s + 2 (MW), window s + 2 (16); younger than slab s + 1 at the
     // barrier: window s + 1, slab s + 2, window s + 2 = 32 + MW.
-    // MFMA order of a stage: lo*hi and hi*hi before the barrier, hi*lo after it; the early fragments of the
-    // next stage (A.lo, B.hi) are read under that last term, which does not use them.
+    // MFMA order of a stage: lo*hi and hi*hi before its barrier, hi*lo after it.  The loop body OPENS right after
+    // a barrier: it reads the early fragments of its stage (A.lo, B.hi) and covers their latency with the hi*lo
+    // term of the PREVIOUS stage, whose A.hi / B.lo are still in registers (zeros before the first stage), so
+    // that read and cover are in one scheduling region whatever the compiler does to the loop.
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) af[0][mt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) bf[1][nt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     int s = 0;
     int ab3 = 0;                                      // s % 3
     for (int c16 = 0; c16 < n16; ++c16) {
@@ -302,6 +307,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
         for (int j = 0; j < KS; ++j, ++s) {
             const int ab_next = ab3 == 2 ? 0 : ab3 + 1;
             const int ab_next2 = ab_next == 2 ? 0 : ab_next + 1;
+            FRAGS_EARLY(ab3, xbuf, j)
+            TERM(0, 1)                                // previous stage
             if (KS != 1 && j == 0) LOAD_X(c16 + 1)
             DMA_A(s + 2, ab_next2)
             FRAGS_LATE(ab3, xbuf, j)
@@ -318,11 +325,10 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
                 }
             }
             if (KS == 1) CH_BARRIER(32 + MW) else if (j == 0) CH_BARRIER(16 + MW) else CH_BARRIER(MW)
-            if (j == KS - 1) FRAGS_EARLY(ab_next, xbuf ^ 1, 0) else FRAGS_EARLY(ab_next, xbuf, j + 1)
-            TERM(0, 1)
             ab3 = ab_next;
         }
     }
+    TERM(0, 1)                                        // last stage
     // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #undef DMA_A
