@@ -5,28 +5,36 @@
 //   KS = 1:  part[split][m][c]       = sum_{s, t in split} A[s][m][t] * X[s][c][t]
 //
 // both operands activations: each is scaled by a power of two taken from its tensor maximum (a_amax / x_amax,
-// device scalars), split into two f16 planes while it is staged, and the partial tile is multiplied by the
+// device amax slots), split into two f16 planes while it is staged, and the partial tile is multiplied by the
 // exact inverse scales on the way out.  Three MFMAs per 32x32x16 block (lo*hi, hi*hi, hi*lo).
 //
 // ONE workgroup of four wavefronts per CU (one per SIMD); a wavefront owns (32 MW) rows x (32 columns x NS
 // "slots") as MW x NS MFMA accumulators; the slots are the three taps of 64 X rows (KS = 3, NS = 3) or NS blocks
 // of 64 X rows (KS = 1).  Tiles: <3,5,3> and <1,5,3> 320 x 192 (weight gradients), <1,4,2> 256 x 128 (ClipLoss
 // scores at batch 256: two column tiles x 128 K-splits fill the chip with 33 MB of partial tiles).
-// Stage = 16 samples = MW + NS pieces of 4 samples per thread (A rows 64 i + row64, then the NS slot copies of the
-// X rows).  Pipeline of a stage k (MFMAs on LDS buffer k & 1):
-//     wait for chunk k + 1 (fetched a whole stage ago)  ->  fetch chunk k + 2 into the other register set  ->
-//     split chunk k + 1 into LDS buffer (k + 1) & 1 between the first 2/3 of the MFMAs (lo*hi, hi*hi)  ->
-//     barrier  ->  early fragments of stage k + 1  ->  last third of the MFMAs (hi*lo).
+//
+// Stage = 32 samples = two MFMA k-steps.  A stage's operands are fetched as FULL 128-byte lines: eight lanes per
+// row (4 samples = 16 bytes each), 32 rows per wave-load pass, 2 MW + 2 NS passes per thread.  (With 16-sample
+// stages a wave-load touches 16 half-lines and the per-CU load path, not the matrix pipe, bounds the kernel:
+// measured 8 bytes / clock / CU, 40 % matrix-pipe busy.)  ONE staging register set; pipeline of stage k (MFMAs on
+// LDS buffer k & 1):
+//     wait for chunk k + 1 (fetched half a stage ago)  ->  split it into LDS buffer (k + 1) & 1 between the MFMAs
+//     of k-step 0  ->  fetch chunk k + 2 into the same registers  ->  k-step 1: lo*hi, hi*hi  ->  barrier  ->
+//     early fragments of stage k + 1 under the last term (hi*lo).
+// Operand fragments roll through one register set: a term's fragments are replaced by those of the next k-step
+// as soon as its MFMAs are issued, so every LDS read is covered by the 15 MFMAs of the term in front of its use.
 // The loads are compiler-visible raw buffer loads: gemm_nt_x3w.hip hides its loads in inline asm with hand-counted
 // waits, which is only sound while the register allocator never copies a register whose load is still in
-// flight -- it did here (v_mov of a staging set ahead of its wait).  hipcc's own waits are conservative around
-// the interior / edge branch of the fetch, so the schedule gives every fetch a full stage before its first use
-// and names all its registers at that point (one wait, nothing left pending when the next fetch is issued).
+// flight -- it did here (v_mov of a staging set ahead of its wait).  hipcc's own waits are conservative around the
+// interior / edge branch of the fetch; with one wait per stage, placed where every outstanding load is at least
+// half a stage old, conservative costs nothing.
 // Rows past M / Cn are addressed through the per-lane offset, which the buffer descriptor range-checks: they
 // read as zeros and are never written, so M and Cn may be padded.
 // LDS (16-byte slots = 8 samples of one plane), two stage buffers of two planes each:
-//   A [2 halves of the 16 samples][64 MW + 8 rows], X [NS slots][2 halves][64 + 8 rows].
+//   A [4 groups of 8 samples][64 MW + 2 rows], X [NS slots][4 groups][64 + 2 rows]   (row counts = 2 mod 8: the
+//   16 lanes of a ds_write_b64 group -- 2 rows x 8 pieces -- land on 16 different bank pairs).
 #include <cstdlib>
+#include <utility>
 #include <cstring>
 #include "bm_common.h"
 
@@ -35,8 +43,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-#define HG_K 16
-#define HG_XQ (64 + 8)                        // slots of one 8-sample half of one X slot (8 pad rows)
+#define HG_K 32                               // samples per stage
+#define HG_XQ (64 + 2)                        // slots of one 8-sample group of one X slot (2 pad rows)
 
 struct GemmNTArgsH {
     const float* a; long a_sstride; long a_rstride;
@@ -92,6 +100,17 @@ __device__ __forceinline__ void hg_split_store4(const float (&f)[4], float s, ch
     *reinterpret_cast<u32x2*>(dst + plane_bytes) = __builtin_bit_cast(u32x2, l);
 }
 
+// two fp32 values -> scaled f16 pairs: hi = f16(x * s), lo = f16(x * s - hi) (the product is exact, s is a power
+// of two; the difference is exact in fp32), written straight into the halves of the packed results: 4 VALU
+__device__ __forceinline__ void hg_split_pair(float x0, float x1, float s0, float s1, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %5, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(x0), "v"(x1), "v"(s0), "v"(s1));
+}
+
 // lgkmcnt(0) + workgroup barrier; names A.hi / B.hi as operands so that the register-only MFMAs that read them
 // stay on their side of the barrier (see conv_nn_h2w.hip)
 template <int MW, int NS>
@@ -106,26 +125,53 @@ __device__ __forceinline__ void hg_barrier(f16x8 (&ah)[MW], f16x8 (&bh)[NS]) {
                      :: "memory");
 }
 
-// "every register of this staging set is needed now": the compiler places its wait for the whole set here
+// "every register of the staging set is needed now": the compiler places its wait for the whole set here
 template <int NP>
 __device__ __forceinline__ void hg_touch(u32x4 (&r)[NP]) {
-    if constexpr (NP == 8)
-        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]));
+    if constexpr (NP == 16)
+        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]),
+                     "v"(r[8]), "v"(r[9]), "v"(r[10]), "v"(r[11]), "v"(r[12]), "v"(r[13]), "v"(r[14]), "v"(r[15]));
     else
-        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]));
+        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]),
+                     "v"(r[8]), "v"(r[9]), "v"(r[10]), "v"(r[11]));
 }
+
+template <int... I, class F>
+__device__ __forceinline__ void hg_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void hg_static_for(F&& f) {
+    hg_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+#ifdef HG_TRACE
+// cycle trace of the stage pipeline (diagnostic builds only, scripts/build_trace_lib.sh): per workgroup and
+// wavefront, cycles summed over the stages of seven segments of the loop body
+__device__ long long hg_trace_buf[64 * 4 * 8];
+#define HG_T(I_) { __builtin_amdgcn_sched_barrier(0); tr[I_] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int bm_debug_trace_read(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hg_trace_buf), sizeof(long long) * 64 * 4 * 8);
+}
+#else
+#define HG_T(I_)
+#endif
 
 template <int KS, int MW, int NS>
 __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     static_assert((MW == 5 && NS == 3) || (MW == 4 && NS == 2), "tile variants: 320 x 192, 256 x 128");
     static_assert(KS == 1 || NS == 3, "3 taps use the 3 slots");
-    constexpr int NP = MW + NS;                       // 4-sample pieces per thread and stage
+    constexpr int NA = 2 * MW;                        // A pieces per thread and stage (32 rows per pass)
+    constexpr int NX = 2 * NS;                        // X pieces (slot j, 32-row half u)
+    constexpr int NP = NA + NX;
     constexpr int BM = 64 * MW;
     constexpr int BC = KS == 3 ? 64 : 64 * NS;        // X rows of the workgroup tile
-    constexpr int AQ = BM + 8;                        // slots of one 8-sample half of the A tile (8 pad rows)
-    constexpr int ASLOTS = 2 * AQ;                    // 16-byte slots of one plane of the A tile
-    constexpr int PLANE = ASLOTS + NS * 2 * HG_XQ;    // ... of one plane (A + X)
+    constexpr int AQ = BM + 2;                        // slots of one 8-sample group of the A tile (2 pad rows)
+    constexpr int ASLOTS = 4 * AQ;                    // 16-byte slots of one plane of the A tile
+    constexpr int PLANE = ASLOTS + NS * 4 * HG_XQ;    // ... of one plane (A + X)
     constexpr int BUF = 2 * PLANE;                    // slots of one stage buffer (2 planes)
+    constexpr int TN = MW * NS;                       // MFMAs of one term (one operand-plane pair, one k-step)
+    constexpr int NXS = KS == 3 ? 3 : 1;              // tap shifts of the X fetches
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* lds = reinterpret_cast<u32x4*>(smem);      // [2 buffers][2 planes][A slots | X slots]
     const int tid = threadIdx.x;
@@ -152,26 +198,26 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     hg_scale_from_amax(bm_amax_load(a.a_amax), sa, sa_inv);
     hg_scale_from_amax(bm_amax_load(a.x_amax), sx, sx_inv);
 
-    // The pieces of this thread: lane -> (row64 = tid >> 2, quarter pq = tid & 3 of the 16 samples).  Piece
-    // i < MW: A row m0 + 64 i + row64; piece MW + j: X row c0 + row64 read at tap shift (j - 1) * dil (KS = 3) or
-    // X row c0 + 64 j + row64 (KS = 1).  Byte offsets inside a segment, all >= 0; a row past M / Cn gets
-    // 0x7f000000: past the range of every descriptor (segments span < 0x7f000000 bytes, checked by the host) and
-    // small enough that adding a chunk offset cannot wrap (reads 0).
-    const int row64 = tid >> 2, pq = tid & 3;
-    int offa[MW], offx[NS];
+    // The pieces of this thread: lane -> (row32 = tid >> 3, piece pl = tid & 7 of the 32 samples).  A piece i:
+    // row m0 + 32 i + row32.  X piece (j, u) = index NA + 2 j + u: row c0 + 32 u + row32 read at tap shift
+    // (j - 1) * dil (KS = 3) or row c0 + 64 j + 32 u + row32 (KS = 1).  Byte offsets inside a segment, all >= 0; a
+    // row past M / Cn gets 0x7f000000: past the range of every descriptor (segments span < 0x7f000000 bytes,
+    // checked by the host) and small enough that adding a chunk offset cannot wrap (reads 0).
+    const int row32 = tid >> 3, pl = tid & 7;
+    int offa[NA], offx[NX];
 #pragma unroll
-    for (int i = 0; i < MW; ++i) {
-        const int m = m0 + 64 * i + row64;
-        offa[i] = m < a.M ? (m * (int)a.a_rstride + 4 * pq) * 4 : 0x7f000000;
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + 32 * i + row32;
+        offa[i] = m < a.M ? (m * (int)a.a_rstride + 4 * pl) * 4 : 0x7f000000;
     }
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int c = c0 + (KS == 3 ? 0 : 64 * j) + row64;
-        offx[j] = c < a.Cn ? (c * (int)a.x_rstride + 4 * pq) * 4 : 0x7f000000;
+    for (int q = 0; q < NX; ++q) {
+        const int c = c0 + (KS == 3 ? 0 : 64 * (q >> 1)) + 32 * (q & 1) + row32;
+        offx[q] = c < a.Cn ? (c * (int)a.x_rstride + 4 * pl) * 4 : 0x7f000000;
     }
-    // LDS byte address inside a plane: 16-byte slot of the 8-sample half (pq >> 1), 8-byte half (pq & 1)
-    const int ldsa = ((pq >> 1) * AQ + row64) * 16 + (pq & 1) * 8;                 // piece i: + i * 64 * 16
-    const int ldsx = (ASLOTS + (pq >> 1) * HG_XQ + row64) * 16 + (pq & 1) * 8;     // slot j: + j * 2 * HG_XQ * 16
+    // LDS byte address inside a plane: 16-byte slot of the 8-sample group (pl >> 1), 8-byte half (pl & 1)
+    const int ldsa = ((pl >> 1) * AQ + row32) * 16 + (pl & 1) * 8;                          // piece i: + i * 32 * 16
+    const int ldsx = (ASLOTS + (pl >> 1) * HG_XQ + row32) * 16 + (pl & 1) * 8;   // piece (j, u): + (j * 4 * HG_XQ + 32 u) * 16
 
     f32x16 acc[MW][NS];
 #pragma unroll
@@ -181,7 +227,22 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[NP], rb[NP];                              // two staging register sets (consumed / in flight)
+    u32x4 rp[NP];                                      // the staging register set
+    // Per-value operand scales: sa / sx, or 0 for a sample outside [0, T) (the dwordx4 fetch of a row's first or
+    // last chunk also brings samples of the neighbouring rows; v_mul_legacy: 0 * anything = 0).  Rewritten only
+    // when the chunk in the staging set is the first or last one of its segment, or follows one.
+    float sva[4], svx[NXS][4];
+#define HG_SET_SCALES(T0_)                                                                        \
+    {                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                           \
+            const int ta = (T0_) + 4 * pl + r;                                                    \
+            sva[r] = ta < a.T ? sa : 0.f;                                                         \
+            _Pragma("unroll") for (int j = 0; j < NXS; ++j) {                                     \
+                const int tx = ta + (KS == 3 ? (j - 1) * a.dil : 0);                              \
+                svx[j][r] = (tx >= 0 && tx < a.T) ? sx : 0.f;                                     \
+            }                                                                                     \
+        }                                                                                         \
+    }
 
     int ld_q = 0;
     int ld_s = (int)(q_begin / cps);
@@ -189,128 +250,178 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     // segment descriptors, rebuilt only when the cursor enters a new segment
     __amdgpu_buffer_rsrc_t qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);
     __amdgpu_buffer_rsrc_t qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);
-
-    // fetches chunk (ld_s, ld_c) into register set R_ and advances the cursor.  Interior chunks: one dwordx4 per
-    // piece.  Edge chunks (first / last of a segment, wave-uniform): one dword per sample, samples whose time
-    // index is outside [0, T) get an out-of-range offset and read as 0.
-#define HG_LOAD(R_)                                                                               \
+    int vn, vx[NXS];                                   // byte offset of the chunk to fetch (X: per tap)
+#define HG_CHUNK_OFFSETS()                                                                        \
     {                                                                                             \
-        const int t0 = ld_c * HG_K;                                                               \
-        if (!(t0 - halo < 0 || t0 + HG_K + halo > a.T)) {                                         \
-            const int s0 = __builtin_amdgcn_readfirstlane(t0 * 4);                                \
-            _Pragma("unroll") for (int i = 0; i < MW; ++i) R_[i] = hg_ld128(qa, offa[i], s0);     \
-            _Pragma("unroll") for (int j = 0; j < NS; ++j)        /* t0 + shift >= 0 in interior chunks */ \
-                R_[MW + j] = hg_ld128(qx, offx[j],                                                \
-                                      KS == 3 ? __builtin_amdgcn_readfirstlane((t0 + (j - 1) * a.dil) * 4) : s0); \
-        } else {                                                                                  \
-            unsigned e_[NP][4];       /* all loads first, the register sets are assembled afterwards */ \
-            _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                      \
-                const __amdgpu_buffer_rsrc_t rs = i < MW ? qa : qx;                               \
-                const int shift = (i < MW || KS != 3) ? 0 : (i - MW - 1) * a.dil;                 \
-                const int tt0 = t0 + 4 * pq + shift;                                              \
-                const int o = (i < MW ? offa[i < MW ? i : 0] : offx[i < MW ? 0 : i - MW]) + (t0 + shift) * 4; \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
-                    const int tt = tt0 + r;                                                       \
-                    const int oo = (tt >= 0 && tt < a.T) ? o + r * 4 : 0x7ffffff0;                \
-                    e_[i][r] = hg_ld32(rs, oo);                                                   \
+        vn = ld_c * (HG_K * 4);                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NXS; ++j) vx[j] = vn + (KS == 3 ? (j - 1) * a.dil * 4 : 0); \
+    }
+#define HG_ADVANCE()                                                                              \
+    if (++ld_q < nst) {                                /* else: stays on the last chunk */        \
+        if (++ld_c == cps) {                                                                      \
+            ld_c = 0; ++ld_s;                                                                     \
+            qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                                \
+            qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                                \
+        }                                                                                         \
+    }
+    // fetch of piece I_ of the chunk at the cursor: the whole offset travels in the per-lane address, which the
+    // descriptor range-checks (a scalar offset is not), so nothing outside the segment is ever read.  A dwordx4
+    // whose first byte lies in front of the segment (first X row, first chunk, tap -dil) comes back as zeros
+    // altogether: those lanes re-fetch it sample by sample.
+#define HG_FETCH(I_)                                                                              \
+    {                                                                                             \
+        if ((I_) < NA) rp[I_] = hg_ld128(qa, offa[(I_) < NA ? (I_) : 0] + vn, 0);                 \
+        else {                                                                                    \
+            const int vo_ = offx[(I_) < NA ? 0 : (I_) - NA] + vx[KS == 3 ? (((I_) - NA) >> 1) % NXS : 0]; \
+            rp[I_] = hg_ld128(qx, vo_, 0);                                                        \
+            if (KS == 3 && (I_) == NA && vn == 0) {                                               \
+                if (vo_ < 0 && vo_ > -16) {                                                       \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                 \
+                        rp[I_][r] = hg_ld32(qx, vo_ + 4 * r < 0 ? 0x7ffffff0 : vo_ + 4 * r);      \
                 }                                                                                 \
             }                                                                                     \
-            _Pragma("unroll") for (int i = 0; i < NP; ++i)                                        \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) R_[i][r] = e_[i][r];                \
-        }                                                                                         \
-        if (++ld_q < nst) {                            /* else: stays on the last chunk */        \
-            if (++ld_c == cps) {                                                                  \
-                ld_c = 0; ++ld_s;                                                                 \
-                qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                            \
-                qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                            \
-            }                                                                                     \
         }                                                                                         \
     }
-    // splits piece I_ of register set R_ into buffer BUF_ (two 8-byte LDS writes, immediate offsets)
-#define HG_STORE(R_, I_, BUF_)                                                                    \
+    // piece I_ of the staging set -> stage buffer at byte address WB_, in three sub-steps that go behind three
+    // consecutive MFMAs: split of samples 0-1, of samples 2-3, two 8-byte LDS writes (+ the fetch that refills it)
+#define HG_SV(I_) ((I_) < NA ? sva : svx[KS == 3 ? (((I_) - NA) >> 1) % NXS : 0])
+#define HG_SPLIT0(I_) hg_split_pair(__uint_as_float(rp[I_][0]), __uint_as_float(rp[I_][1]), HG_SV(I_)[0], HG_SV(I_)[1], ph[0], pw[0]);
+#define HG_SPLIT1(I_) hg_split_pair(__uint_as_float(rp[I_][2]), __uint_as_float(rp[I_][3]), HG_SV(I_)[2], HG_SV(I_)[3], ph[1], pw[1]);
+#define HG_WRITE(I_, WB_)                                                                         \
     {                                                                                             \
-        char* dst_ = reinterpret_cast<char*>(lds + (BUF_) * BUF) +                                \
-                     ((I_) < MW ? ldsa + (I_) * 64 * 16 : ldsx + ((I_) - MW) * 2 * HG_XQ * 16);   \
-        float f_[4];                                                                              \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) f_[r] = __uint_as_float(R_[I_][r]);         \
-        hg_split_store4(f_, (I_) < MW ? sa : sx, dst_, PLANE * 16);                               \
+        char* dst_ = (WB_) + ((I_) < NA ? ldsa + (I_) * 32 * 16                                   \
+                                        : ldsx + ((((I_) - NA) >> 1) * 4 * HG_XQ + 32 * (((I_) - NA) & 1)) * 16); \
+        *reinterpret_cast<u32x2*>(dst_) = u32x2{ph[0], ph[1]};                                    \
+        *reinterpret_cast<u32x2*>(dst_ + PLANE * 16) = u32x2{pw[0], pw[1]};                       \
     }
-#define HG_STORE_ALL(R_, BUF_)                                                                    \
-    {                                                                                             \
-        HG_STORE(R_, 0, BUF_) HG_STORE(R_, 1, BUF_) HG_STORE(R_, 2, BUF_) HG_STORE(R_, 3, BUF_)   \
-        HG_STORE(R_, 4, BUF_) HG_STORE(R_, 5, BUF_)                                               \
-        if constexpr (NP == 8) { HG_STORE(R_, 6, BUF_) HG_STORE(R_, 7, BUF_) }                    \
-    }
-#define HG_TERM(PA_, PB_)                                                                         \
+#define HG_STORE(I_, WB_) { HG_SPLIT0(I_) HG_SPLIT1(I_) HG_WRITE(I_, WB_) }
+    unsigned ph[2], pw[2];
+    // one operand fragment set, rolling over the k-steps: [plane 0 = hi, 1 = lo]; k-step KK_ of the stage in
+    // buffer RB_ (u32x4*): group 2 KK_ + h of the lane's row
+#define HG_READ_A(P_, RB_, KK_)                                                                   \
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
-        _Pragma("unroll") for (int j = 0; j < NS; ++j)                                            \
-            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA_][mt], bf[PB_][j], acc[mt][j], 0, 0, 0);
-    // Operand fragments live across stages: [plane 0 = hi, 1 = lo].
+        af[P_][mt] = __builtin_bit_cast(f16x8, (RB_)[(P_) * PLANE + (2 * (KK_) + h) * AQ + wm * (MW * 32) + mt * 32 + nl]);
+#define HG_READ_B(P_, RB_, KK_)                                                                   \
+    _Pragma("unroll") for (int j = 0; j < NS; ++j)                                                \
+        bf[P_][j] = __builtin_bit_cast(f16x8, (RB_)[(P_) * PLANE + ASLOTS + (j * 4 + 2 * (KK_) + h) * HG_XQ + wc * 32 + nl]);
+#define HG_READ_A1(P_, RB_, KK_, MT_)                                                             \
+    af[P_][MT_] = __builtin_bit_cast(f16x8, (RB_)[(P_) * PLANE + (2 * (KK_) + h) * AQ + wm * (MW * 32) + (MT_) * 32 + nl]);
+#define HG_READ_B1(P_, RB_, KK_, J_)                                                              \
+    bf[P_][J_] = __builtin_bit_cast(f16x8, (RB_)[(P_) * PLANE + ASLOTS + ((J_) * 4 + 2 * (KK_) + h) * HG_XQ + wc * 32 + nl]);
     f16x8 af[2][MW], bf[2][NS];
-    // fragments a stage needs first (A.lo, B.hi), read from buffer BUF_ as soon as it is complete
-#define HG_FRAGS_EARLY(BUF_)                                                                      \
-    {                                                                                             \
-        const u32x4* pb = lds + (BUF_) * BUF;                                                     \
-        const u32x4* ab = pb + h * AQ + wm * (MW * 32) + nl;                                      \
-        const u32x4* xb = pb + ASLOTS + h * HG_XQ + wc * 32 + nl;                                 \
-        _Pragma("unroll") for (int j = 0; j < NS; ++j) bf[0][j] = __builtin_bit_cast(f16x8, xb[j * 2 * HG_XQ]); \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(f16x8, ab[PLANE + mt * 32]); \
-    }
-    // One stage k on buffer BUF_; P_ holds chunk k + 1 (fetched a stage ago), Q_ receives chunk k + 2.  Every
-    // stage does all of it, the last ones on clamped (repeated) chunks whose results are never read.
-#define HG_STAGE(BUF_, NBUF_, P_, Q_)                                                             \
-    {                                                                                             \
-        hg_touch<NP>(P_);             /* the one wait of the stage */                             \
-        HG_LOAD(Q_)                   /* its interior / edge branch ends the scheduling region */ \
-        const u32x4* pb = lds + (BUF_) * BUF;                                                     \
-        const u32x4* ab = pb + h * AQ + wm * (MW * 32) + nl;                                      \
-        const u32x4* xb = pb + ASLOTS + h * HG_XQ + wc * 32 + nl;                                 \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(f16x8, ab[mt * 32]); \
-        _Pragma("unroll") for (int j = 0; j < NS; ++j) bf[1][j] = __builtin_bit_cast(f16x8, xb[PLANE + j * 2 * HG_XQ]); \
-        HG_STORE_ALL(P_, NBUF_)                                                                   \
-        HG_TERM(1, 0)                                                                             \
-        HG_TERM(0, 0)                                                                             \
-        _Pragma("unroll") for (int g_ = 0; g_ < 2 * MW * NS; ++g_) {                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                    \
-            if (g_ & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        \
-        }                                                                                         \
-        hg_barrier<MW, NS>(af[0], bf[0]);                                                         \
-        HG_FRAGS_EARLY(NBUF_)                                                                     \
-        HG_TERM(0, 1)                                                                             \
-    }
 
     if (nst > 0) {
-        HG_LOAD(ra)
-        HG_LOAD(rb)
-        HG_STORE_ALL(ra, 0)
+        // chunk 0 -> buffer 0, chunk 1 -> staging set
+        HG_CHUNK_OFFSETS()
+        int t0c = ld_c * HG_K;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) HG_FETCH(i)
+        HG_ADVANCE()
+        HG_SET_SCALES(t0c)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) HG_STORE(i, reinterpret_cast<char*>(lds))
+        HG_CHUNK_OFFSETS()
+        t0c = ld_c * HG_K;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) HG_FETCH(i)
+        HG_ADVANCE()
         __syncthreads();
-        HG_FRAGS_EARLY(0)
-        // stages in pairs (the two register sets and the two LDS buffers swap roles every stage), an odd last
-        // stage after the loop: no conditional inside the loop body
-        for (int k = 0; k + 1 < nst; k += 2) {
-            HG_STAGE(0, 1, rb, ra)
-            HG_STAGE(1, 0, ra, rb)
+        HG_READ_A(1, lds, 0)
+        HG_READ_B(0, lds, 0)
+        bool was_edge = true;
+#ifdef HG_TRACE
+        unsigned long long tr[8], tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        // stage k: MFMAs on buffer k & 1 -- six terms of MW NS MFMAs: k-step 0 lo*hi, hi*hi, hi*lo, k-step 1
+        // likewise; the staging set holds chunk k + 1 (fetched during stage k - 1; a repeat of the last chunk in
+        // the last stage: split and stored like any other, never read).  Spread over the first five terms, piece
+        // by piece: split the piece into buffer (k + 1) & 1, fetch the same piece of chunk k + 2 into its
+        // registers.  Barrier before the last term, which covers the first fragment reads of stage k + 1.
+        for (int k = 0; k < nst; ++k) {
+            HG_T(0)
+            const u32x4* rb = lds + (k & 1) * BUF;
+            const u32x4* nb = lds + ((k + 1) & 1) * BUF;
+            char* wb = reinterpret_cast<char*>(lds + ((k + 1) & 1) * BUF);
+            const bool edge = t0c - halo < 0 || t0c + HG_K + halo > a.T;
+            if (edge || was_edge) HG_SET_SCALES(t0c)
+            was_edge = edge;
+            HG_CHUNK_OFFSETS()
+            t0c = ld_c * HG_K;
+            HG_T(1)
+            // One slot per MFMA, in source order (scheduling fence after each): the MFMA, then at most one
+            // fragment read and one sub-step of a piece -- a lone wavefront per SIMD issues one instruction every
+            // 8 cycles, so an MFMA (32 cycles) hides 3 more, and a burst of anything else leaves the matrix pipe idle
+            // (measured with the cycle trace of scripts/trace_wgrad.py: 16 fetches issued back to back block the
+            // wavefront for 2 000 cycles).  Fragments roll through one register set: each is re-read for the next
+            // k-step right behind the last MFMA that uses it.
+            hg_static_for<6 * TN>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                constexpr int term = n / TN, w = n % TN, mt = w / NS, j = w % NS;
+                constexpr int pa = term % 3 == 0 ? 1 : 0, pb = term % 3 == 2 ? 1 : 0;
+                if constexpr (n == 5 * TN) {
+                    HG_T(4)
+                    hg_barrier<MW, NS>(af[0], bf[0]);
+                    HG_T(5)
+                }
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[pa][mt], bf[pb][j], acc[mt][j], 0, 0, 0);
+                // fragment reads
+                if constexpr (term == 0) {
+                    if constexpr (w < MW) HG_READ_A1(0, rb, 0, w)                        // late fragments of k-step 0:
+                    else if constexpr (w < MW + NS) HG_READ_B1(1, rb, 0, w - MW)         // A.hi, B.lo
+                }
+                if constexpr (term == 0 && j == NS - 1 && w >= MW + NS) HG_READ_A1(1, rb, 1, mt)   // A.lo: last use
+                if constexpr (term == 1 && w == TN - 1) {
+                    // A.lo fragments whose slot was taken by the late reads above
+                    hg_static_for<MW>([&](auto mc) __attribute__((always_inline)) {
+                        constexpr int m2 = decltype(mc)::value;
+                        if constexpr (m2 * NS + NS - 1 < MW + NS) HG_READ_A1(1, rb, 1, m2)
+                    });
+                }
+                if constexpr (term == 1 && mt == MW - 1) HG_READ_B1(0, rb, 1, j)         // B.hi: last use
+                if constexpr (term == 2 && j == NS - 1) HG_READ_A1(0, rb, 1, mt)         // A.hi
+                if constexpr (term == 2 && mt == MW - 1) HG_READ_B1(1, rb, 1, j)         // B.lo
+                if constexpr (term == 5) {                                                // early fragments of k + 1
+                    if constexpr (w < MW) HG_READ_A1(1, nb, 0, w)
+                    else if constexpr (w < MW + NS) HG_READ_B1(0, nb, 0, w - MW)
+                }
+                // piece p: sub-steps behind MFMAs p * 5 TN / NP + 0, 1, 2
+                if constexpr (n < 5 * TN) {
+                    constexpr int p = ((n + 1) * NP + 5 * TN - 1) / (5 * TN) - 1;        // last piece starting at <= n
+                    constexpr int n0 = p * 5 * TN / NP;
+                    if constexpr (n == n0) HG_SPLIT0(p)
+                    if constexpr (n == n0 + 1) HG_SPLIT1(p)
+                    if constexpr (n == n0 + 2) {
+                        HG_WRITE(p, wb)
+                        HG_FETCH(p)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            HG_ADVANCE()
+#ifdef HG_TRACE
+            HG_T(6)
+            tacc[0] += tr[1] - tr[0]; tacc[1] += tr[4] - tr[1]; tacc[4] += tr[5] - tr[4]; tacc[5] += tr[6] - tr[5];
+            tacc[7] += 1;
+#endif
         }
-        if (nst & 1) {                 // last stage: nothing left to fetch or split
-            const u32x4* pb = lds;
-            const u32x4* ab = pb + h * AQ + wm * (MW * 32) + nl;
-            const u32x4* xb = pb + ASLOTS + h * HG_XQ + wc * 32 + nl;
-#pragma unroll
-            for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(f16x8, ab[mt * 32]);
-#pragma unroll
-            for (int j = 0; j < NS; ++j) bf[1][j] = __builtin_bit_cast(f16x8, xb[PLANE + j * 2 * HG_XQ]);
-            HG_TERM(1, 0)
-            HG_TERM(0, 0)
-            HG_TERM(0, 1)
-        }
+#ifdef HG_TRACE
+        if (blockIdx.x < 64 && lane == 0)
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) hg_trace_buf[(blockIdx.x * 4 + wave) * 8 + i_] = (long long)tacc[i_];
+#endif
     }
-#undef HG_LOAD
-#undef HG_FRAGS_EARLY
+#undef HG_SET_SCALES
+#undef HG_CHUNK_OFFSETS
+#undef HG_ADVANCE
+#undef HG_FETCH
 #undef HG_STORE
-#undef HG_STORE_ALL
-#undef HG_TERM
-#undef HG_STAGE
+#undef HG_SV
+#undef HG_SPLIT0
+#undef HG_SPLIT1
+#undef HG_WRITE
+#undef HG_READ_A1
+#undef HG_READ_B1
+#undef HG_READ_A
+#undef HG_READ_B
 
     // partial tile out (inverse scales are exact powers of two): KS = 3: part[split][m][c * 3 + j];
     // KS = 1: part[split][m][c0 + 64 j + ...]
@@ -352,7 +463,7 @@ static int hg_family(int S, int G, int M, int Cn, int T, int KS, int dil, bool o
     }
     if (!wide || G != 1 || ordered || (KS != 3 && KS != 1)) return 0;
     if (dil < 1 || dil > 32 || T < 2 * HG_K) return 0;
-    if ((long)S * ((T + HG_K - 1) / HG_K) < 64) return 0;
+    if ((long)S * ((T + HG_K - 1) / HG_K) < 32) return 0;
     // padded rows / columns are wasted MFMA work: at most 25 % (3 taps) / 50 % (1x1 layers, small in absolute terms)
     const long work = (long)M * Cn;
     const long pad53 = (long)cdiv(M, 320) * 320 * cdiv(Cn, KS == 3 ? 64 : 192) * (KS == 3 ? 64 : 192);
@@ -366,20 +477,20 @@ extern "C" int bm_gemm_nt_h2_covers(int M, int Cn, int KS, int S, int T, int G, 
     return hg_family(S, G, M, Cn, T, KS, dil, ordered != 0) ? 1 : 0;
 }
 
-// one workgroup per CU per round (256 CUs), >= 16 stages per workgroup
+// one workgroup per CU per round (256 CUs), >= 8 stages (of 32 samples) per workgroup
 extern "C" int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T) {
     const int fam = hg_family(S, 1, M, Cn, T, KS, 1, false);
     const int tiles = fam == 2 ? cdiv(M, 256) * cdiv(Cn, 128) : cdiv(M, 320) * cdiv(Cn, KS == 3 ? 64 : 192);
     const long chunks = (long)S * ((T + HG_K - 1) / HG_K);
     long want = 256 / tiles;
-    if (want > chunks / 16) want = chunks / 16;
+    if (want > chunks / 8) want = chunks / 8;
     if (want < 1) want = 1;
     return (int)want;
 }
 
 template <int KS, int MW, int NS>
 static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
-    constexpr int PLANE = 2 * (64 * MW + 8) + NS * 2 * HG_XQ;
+    constexpr int PLANE = 4 * (64 * MW + 2) + NS * 4 * HG_XQ;
     const size_t lds = (size_t)2 * 2 * PLANE * 16;
     static bool attr_set = false;
     if (!attr_set) {

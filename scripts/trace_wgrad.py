@@ -1,0 +1,34 @@
+"""Cycle trace of the wide weight-gradient kernel (diagnostic library built by scripts/build_trace_lib.sh):
+BM_HIP_LIB=brainmagick_amd/libbmhip_trace.so python scripts/trace_wgrad.py"""
+import ctypes
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import brainmagick_amd  # noqa: E402
+from brainmagick_amd import hip_ops as H  # noqa: E402
+
+B, T = 256, 360
+SEG = ["wait loads", "k-step 0 + split", "fetch issue", "k-step 1 (30 MFMA)", "barrier", "early frags + 15 MFMA"]
+g = torch.Generator().manual_seed(0)
+for Cin, M, KS, dil in [(320, 320, 3, 2), (320, 640, 1, 1)]:
+    x = torch.randn(B, Cin, T, generator=g).cuda()
+    dy = torch.randn(B, M, T, generator=g).cuda()
+    brainmagick_amd.set_compute_dtype("f16x2")
+    for _ in range(3):
+        H.gemm_nt(dy, x, B, M, Cin, T, KS, dil)
+    torch.cuda.synchronize()
+    out = (ctypes.c_longlong * (64 * 4 * 8))()
+    rc = H.lib().bm_debug_trace_read(out)
+    assert rc == 0, rc
+    tr = torch.tensor(list(out), dtype=torch.float64).view(64, 4, 8)
+    n = tr[..., 7].clamp(min=1)
+    per = tr[..., :6] / n[..., None]
+    print(f"wgrad Cin={Cin} M={M} KS={KS}: stages/workgroup {n[0, 0].item():.0f}; cycles per stage "
+          f"{per.sum(-1).mean().item():.0f} (clock64 units)")
+    for i, name in enumerate(SEG):
+        print(f"  {name:24s} mean {per[..., i].mean().item():8.0f}  min {per[..., i].min().item():8.0f}  "
+              f"max {per[..., i].max().item():8.0f}")
+    print("  per wave of workgroup 0:", [[round(v) for v in per[0, w].tolist()] for w in range(4)])
