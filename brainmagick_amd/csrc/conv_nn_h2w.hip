@@ -22,6 +22,7 @@
 // per-row inverse scales [G][Mpad] fp32 (bm_pack_weights_h2).
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include "conv_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -67,6 +68,26 @@ __device__ __forceinline__ void split8h(const float* f, float s, u32x4& hi, u32x
     }
     hi = __builtin_bit_cast(u32x4, h);
     lo = __builtin_bit_cast(u32x4, l);
+}
+
+// two fp32 values -> scaled f16 pairs: hi = f16(x * s), lo = f16(x * s - hi) (the product is exact, s is a power
+// of two; the difference is exact in fp32), written straight into the halves of the packed results: 4 VALU
+__device__ __forceinline__ void ch_split_pair(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(x0), "v"(x1), "v"(s));
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void h2_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void h2_static_for(F&& f) {
+    h2_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 __device__ __forceinline__ float ch_ld32(i32x4h rs, int voff) {
@@ -150,6 +171,18 @@ __device__ __forceinline__ void h2_barrier(f16x8 (&ah)[MW], f16x8 (&bh)[3]) {
                      : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
                      : "n"(N) : "memory");
 }
+
+#ifdef HG_TRACE
+// cycle trace of the stage pipeline (diagnostic builds only, scripts/build_trace_lib.sh): per workgroup and
+// wavefront, [tap j][segment] cycles summed over the stages, [3][7] = stage count
+__device__ unsigned ch_trace_buf[64 * 4 * 24];
+#define CH_T(I_) { __builtin_amdgcn_sched_barrier(0); tr[I_] = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int bm_debug_trace_read_conv(unsigned* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ch_trace_buf), sizeof(unsigned) * 64 * 4 * 24);
+}
+#else
+#define CH_T(I_)
+#endif
 
 template <int KS, int MW>
 __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
@@ -248,31 +281,19 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
             xd[(1 * 2 + kg) * HXWP] = lo;                                                         \
         }                                                                                         \
     }
-    // fragments a stage needs first (A.lo, B.hi); ABUF_ = its A buffer, XB_/J_ = its X buffer and tap
-#define FRAGS_EARLY(ABUF_, XB_, J_)                                                               \
-    {                                                                                             \
-        const u32x4* ab = As + (ABUF_) * HASLAB + h * HBM + wm * (MW * 32) + nl;                  \
-        const u32x4* xb = Xs + (XB_) * HXSLAB + h * HXWP + wn * (NW * 32) + nl + (J_) * a.dil;    \
-        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[0][nt] = __builtin_bit_cast(f16x8, xb[0 * 2 * HXWP + nt * 32]); \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[1][mt] = __builtin_bit_cast(f16x8, ab[1 * 2 * HBM + mt * 32]); \
-    }
-#define FRAGS_LATE(ABUF_, XB_, J_)                                                                \
-    {                                                                                             \
-        const u32x4* ab = As + (ABUF_) * HASLAB + h * HBM + wm * (MW * 32) + nl;                  \
-        const u32x4* xb = Xs + (XB_) * HXSLAB + h * HXWP + wn * (NW * 32) + nl + (J_) * a.dil;    \
-        _Pragma("unroll") for (int mt = 0; mt < MW; ++mt) af[0][mt] = __builtin_bit_cast(f16x8, ab[0 * 2 * HBM + mt * 32]); \
-        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt) bf[1][nt] = __builtin_bit_cast(f16x8, xb[1 * 2 * HXWP + nt * 32]); \
-    }
+    // single fragments of the stage in A buffer ABUF_ / X buffer XB_, tap J_ (plane 0 = hi, 1 = lo)
+#define FRAG_A(P_, ABUF_, MT_)                                                                    \
+    af[P_][MT_] = __builtin_bit_cast(f16x8, As[(ABUF_) * HASLAB + ((P_) * 2 + h) * HBM + wm * (MW * 32) + nl + (MT_) * 32]);
+#define FRAG_B(P_, XB_, J_, NT_)                                                                  \
+    bf[P_][NT_] = __builtin_bit_cast(f16x8, Xs[(XB_) * HXSLAB + ((P_) * 2 + h) * HXWP + wn * (NW * 32) + nl + (J_) * a.dil + (NT_) * 32]);
+    // "slab s + 1 landed" + workgroup barrier: N_ younger VMEM instructions may stay in flight.  The statement
+    // names the A.hi and B.hi fragments as read-write operands: the compiler moves register-only MFMAs freely
+    // across an asm statement ("memory" does not order them), and this pins the readers of B.hi before it.
+#define CH_BARRIER(N_) h2_barrier<N_, MW>(af[0], bf[0]);
 #define TERM(PA_, PB_)                                                                            \
     _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
         _Pragma("unroll") for (int nt = 0; nt < NW; ++nt)                                         \
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA_][mt], bf[PB_][nt], acc[mt][nt], 0, 0, 0);
-    // "slab s + 1 landed" + workgroup barrier: N_ younger VMEM instructions may stay in flight.  The statement
-    // names the A.hi and B.hi fragments as read-write operands: the compiler moves register-only MFMAs freely
-    // across an asm statement ("memory" does not order them), and this pins lo*hi / hi*hi (readers of B.hi)
-    // before the barrier and hi*lo (reader of A.hi) after it, where it covers the LDS latency of the next
-    // stage's early fragments.
-#define CH_BARRIER(N_) h2_barrier<N_, MW>(af[0], bf[0]);
 
     // prologue: slabs 0 and 1, input window of chunk 0
     DMA_A(0, 0)
@@ -283,51 +304,120 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     if (KS == 1) LOAD_X(1)          // 1x1 convs: the window of chunk c + 2 is requested in stage c (see below)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // Stage s = (16-channel chunk c16, tap j), A buffer s % 3, X buffer c16 & 1.  VMEM queue order inside a
-    // stage: [input window of chunk c16 + 1, 16 loads, if j == 0], slab s + 2 (MW DMA copies).  Before the
-    // barrier slab s + 1 must have landed: younger than it are MW (+ 16 if j == 0) instructions.  The input
-    // window is consumed in the stage with j == KS - 1: younger than it are the KS slabs issued since.
-    // KS == 1 (every stage is a window stage): the window of chunk c + 1 was requested in stage c - 1 after its
-    // slab; it is split in stage c, and only then is the window of chunk c + 2 requested into the same
-    // registers - queue order per stage: slab s + 2 (MW), window s + 2 (16); younger than slab s + 1 at the
-    // barrier: window s + 1, slab s + 2, window s + 2 = 32 + MW.
-    // MFMA order of a stage: lo*hi and hi*hi before its barrier, hi*lo after it.  The loop body OPENS right after
-    // a barrier: it reads the early fragments of its stage (A.lo, B.hi) and covers their latency with the hi*lo
-    // term of the PREVIOUS stage, whose A.hi / B.lo are still in registers (zeros before the first stage), so
-    // that read and cover are in one scheduling region whatever the compiler does to the loop.
+    // Stage s = (16-channel chunk c16, tap j), A buffer s % 3, X buffer c16 & 1; 3 MW NW MFMAs in three terms:
+    // hi*lo of the PREVIOUS stage (operands still in registers; zeros before the first stage), lo*hi, hi*hi, then
+    // the barrier.  One slot per MFMA, in source order (scheduling fence after each): a lone wavefront per SIMD
+    // issues one instruction every 8 cycles, so an MFMA (32 cycles) hides about 3 more, and anything issued in a
+    // burst -- 16 window loads, a read that is waited for at once -- leaves the matrix pipe idle (cycle trace:
+    // scripts/trace_conv.py).  Behind the MFMAs of a stage, at most a few instructions each:
+    //   term 0: the stage's first fragments (B.hi, A.lo);
+    //   term 1: the MW DMA copies of slab s + 2, the A.hi / B.lo fragments (term 2 / the next stage's term 0), and
+    //     3 taps, j == 0:      the 16 loads of the input window of chunk c16 + 1;
+    //     3 taps, j == KS - 1: that window, split pair by pair into X buffer (c16 + 1) & 1;
+    //     1x1:                 window c16 + 1 (requested in stage c16 - 1) split pair by pair, each pair's
+    //                          registers refilled with window c16 + 2 right behind.
+    // VMEM queue order of a stage: slab s + 2 (MW copies), then the window loads.  Counted waits: the window is
+    // consumed behind the copies of its stage (3 taps: younger are the copies of stages j = 1, 2; 1x1: this
+    // stage's copies); at the barrier slab s + 1 must have landed: younger are this stage's copies and the window
+    // loads issued since (3 taps: j = 0 and j = 1; 1x1: the window just waited for is older than nothing needed).
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) af[0][mt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) bf[1][nt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int TN = MW * NW;
+    constexpr int WS0 = TN + MW, WSN = 2 * TN - MW;   // slots behind the copies: [WS0, WS0 + WSN)
+    unsigned ph[4], pw[4];                            // one 8-channel group of the window being split
     int s = 0;
     int ab3 = 0;                                      // s % 3
+#ifdef HG_TRACE
+    unsigned tr[8], tacc[3][8];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) tacc[i][k] = 0;
+#endif
     for (int c16 = 0; c16 < n16; ++c16) {
         const int xbuf = c16 & 1;
-#pragma unroll
-        for (int j = 0; j < KS; ++j, ++s) {
+        h2_static_for<KS>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            CH_T(0)
             const int ab_next = ab3 == 2 ? 0 : ab3 + 1;
             const int ab_next2 = ab_next == 2 ? 0 : ab_next + 1;
-            FRAGS_EARLY(ab3, xbuf, j)
-            TERM(0, 1)                                // previous stage
-            if (KS != 1 && j == 0) LOAD_X(c16 + 1)
-            DMA_A(s + 2, ab_next2)
-            FRAGS_LATE(ab3, xbuf, j)
-            if (j == KS - 1) {
-                if (KS == 1) CH_WAIT_X(MW) else CH_WAIT_X(KS * MW)
-                STORE_X(xbuf ^ 1)
-                if (KS == 1) LOAD_X(c16 + 2)
-            }
-            TERM(1, 0) TERM(0, 0)
-            if (j == KS - 1) {       // spread the split arithmetic of the input window between the MFMAs
-                _Pragma("unroll") for (int g_ = 0; g_ < 6 * MW; ++g_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            // source of slab s + 2 (clamped to the last stage) and of the window to request
+            const int sc = s + 2 < nstage ? s + 2 : nstage - 1;
+            const int dc16 = sc / KS, djj = sc - dc16 * KS;
+            const u32x4* dsrc = wg + ((long)((dc16 >> 1) * KS + djj) * 8 + (dc16 & 1) * 2) * a.Mpad;
+            const int cb = (c16 + (KS == 1 ? 2 : 1)) * 16 * crow + xoff0;
+            u32x4* xd = Xs + (xbuf ^ 1) * HXSLAB + tid;
+            h2_static_for<3 * TN>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                constexpr int term = n / TN, w = n % TN, mt = w / NW, nt = w % NW;
+                constexpr int pa = term == 1 ? 1 : 0, pb = term == 0 ? 1 : 0;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[pa][mt], bf[pb][nt], acc[mt][nt], 0, 0, 0);
+                if constexpr (term == 0) {                                 // the stage's first fragments
+                    if constexpr (w < NW) FRAG_B(0, xbuf, j, w)
+                    else if constexpr (w < NW + MW) FRAG_A(1, ab3, w - NW)
                 }
-            }
-            if (KS == 1) CH_BARRIER(32 + MW) else if (j == 0) CH_BARRIER(16 + MW) else CH_BARRIER(MW)
+                // A.hi / B.lo (free once term 0 is issued) behind the copies: every wait on LDS data is an
+                // lgkmcnt(0), so no read may be issued right in front of the first MFMA of a term
+                if constexpr (n >= TN + MW && n < TN + 2 * MW) FRAG_A(0, ab3, n - TN - MW)
+                if constexpr (n >= TN + 2 * MW && n < TN + 2 * MW + NW) FRAG_B(1, xbuf, j, n - TN - 2 * MW)
+                if constexpr (term == 1 && w < MW) {                       // DMA piece w of slab s + 2
+                    constexpr int k4 = w;
+                    const int k = wave + 4 * k4;
+                    const int run = k / MW, rb = k - run * MW;             // run = plane * 2 + group
+                    __builtin_amdgcn_global_load_lds(
+                        (const void*)(dsrc + (long)((run >> 1) * 4 + (run & 1)) * a.Mpad + rb * 64),
+                        (__attribute__((address_space(3))) void*)(As + ab_next2 * HASLAB + run * HBM + rb * 64), 16, 0, 0);
+                }
+                if constexpr (n >= WS0) {
+                    constexpr int q = n - WS0;
+                    if constexpr (KS != 1 && j == 0) {                     // window loads, 16 over WSN slots
+                        constexpr int r0 = (q * 16 + WSN - 1) / WSN, r1 = ((q + 1) * 16 + WSN - 1) / WSN;
+                        h2_static_for<r1 - r0>([&](auto rc) __attribute__((always_inline)) {
+                            constexpr int r = r0 + decltype(rc)::value;
+                            if constexpr (r < 16) xreg[r] = ch_ld32(xr, cb + r * crow);
+                        });
+                    }
+                    if constexpr (KS == 1 || j == KS - 1) {                // split units, 8 over WSN slots
+                        if constexpr (q == 0) {
+                            if (KS == 1) CH_WAIT_X(MW) else CH_WAIT_X(2 * MW)
+                        }
+                        constexpr int u0 = (q * 8 + WSN - 1) / WSN, u1 = ((q + 1) * 8 + WSN - 1) / WSN;
+                        h2_static_for<u1 - u0>([&](auto uc) __attribute__((always_inline)) {
+                            constexpr int u = u0 + decltype(uc)::value;
+                            if constexpr (u < 8) {
+                                // the group of pairs 0-3 is written one unit late: not in front of term 2's wait
+                                if constexpr (u == 4) {
+                                    xd[(0 * 2 + 0) * HXWP] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                                    xd[(1 * 2 + 0) * HXWP] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                                }
+                                ch_split_pair(xreg[2 * u], xreg[2 * u + 1], sx, ph[u & 3], pw[u & 3]);
+                                if constexpr (u == 7) {
+                                    xd[(0 * 2 + 1) * HXWP] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                                    xd[(1 * 2 + 1) * HXWP] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                                }
+                                if constexpr (KS == 1) {
+                                    xreg[2 * u] = ch_ld32(xr, cb + (2 * u) * crow);
+                                    xreg[2 * u + 1] = ch_ld32(xr, cb + (2 * u + 1) * crow);
+                                }
+                            }
+                        });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            CH_T(4)
+            if (KS == 1) CH_BARRIER(16 + MW) else if (j == KS - 1) CH_BARRIER(MW) else CH_BARRIER(16 + MW)
+            CH_T(5)
+#ifdef HG_TRACE
+            tacc[j][0] += tr[4] - tr[0]; tacc[j][4] += tr[5] - tr[4]; tacc[j][7] += 1;
+#endif
             ab3 = ab_next;
-        }
+            ++s;
+        });
     }
+#ifdef HG_TRACE
+    if (blockIdx.x < 64 && lane == 0)
+        for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) ch_trace_buf[((blockIdx.x * 4 + wave) * 3 + i) * 8 + k] = tacc[i][k];
+#endif
     TERM(0, 1)                                        // last stage
     // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -335,8 +425,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
 #undef LOAD_X
 #undef CH_WAIT_X
 #undef STORE_X
-#undef FRAGS_EARLY
-#undef FRAGS_LATE
+#undef FRAG_A
+#undef FRAG_B
 #undef TERM
 #undef CH_BARRIER
 

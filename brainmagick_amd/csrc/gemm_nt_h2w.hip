@@ -268,11 +268,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     // descriptor range-checks (a scalar offset is not), so nothing outside the segment is ever read.  A dwordx4
     // whose first byte lies in front of the segment (first X row, first chunk, tap -dil) comes back as zeros
     // altogether: those lanes re-fetch it sample by sample.
+#define HG_Q(I_) ((I_) < NA ? 0 : (I_) - NA)     /* X piece index of staging piece I_ */
 #define HG_FETCH(I_)                                                                              \
     {                                                                                             \
         if ((I_) < NA) rp[I_] = hg_ld128(qa, offa[(I_) < NA ? (I_) : 0] + vn, 0);                 \
         else {                                                                                    \
-            const int vo_ = offx[(I_) < NA ? 0 : (I_) - NA] + vx[KS == 3 ? (((I_) - NA) >> 1) % NXS : 0]; \
+            const int vo_ = offx[(I_) < NA ? 0 : (I_) - NA] + vx[KS == 3 ? (HG_Q(I_) >> 1) % NXS : 0]; \
             rp[I_] = hg_ld128(qx, vo_, 0);                                                        \
             if (KS == 3 && (I_) == NA && vn == 0) {                                               \
                 if (vo_ < 0 && vo_ > -16) {                                                       \
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     }
     // piece I_ of the staging set -> stage buffer at byte address WB_, in three sub-steps that go behind three
     // consecutive MFMAs: split of samples 0-1, of samples 2-3, two 8-byte LDS writes (+ the fetch that refills it)
-#define HG_SV(I_) ((I_) < NA ? sva : svx[KS == 3 ? (((I_) - NA) >> 1) % NXS : 0])
+#define HG_SV(I_) ((I_) < NA ? sva : svx[KS == 3 ? (HG_Q(I_) >> 1) % NXS : 0])
 #define HG_SPLIT0(I_) hg_split_pair(__uint_as_float(rp[I_][0]), __uint_as_float(rp[I_][1]), HG_SV(I_)[0], HG_SV(I_)[1], ph[0], pw[0]);
 #define HG_SPLIT1(I_) hg_split_pair(__uint_as_float(rp[I_][2]), __uint_as_float(rp[I_][3]), HG_SV(I_)[2], HG_SV(I_)[3], ph[1], pw[1]);
 #define HG_WRITE(I_, WB_)                                                                         \
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #undef HG_CHUNK_OFFSETS
 #undef HG_ADVANCE
 #undef HG_FETCH
+#undef HG_Q
 #undef HG_STORE
 #undef HG_SV
 #undef HG_SPLIT0

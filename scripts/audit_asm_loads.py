@@ -30,10 +30,18 @@ def audit_text(asm: str):
         name, body = m.group(1), m.group(2).splitlines()
         inflight = {}
         in_asm = False
+        is_barrier = False
         for ln, line in enumerate(body):
             t = line.strip()
             if t.startswith(";;#ASMSTART"):
                 in_asm = True
+                # the barrier statement's vmcnt(N) only covers the weight slab: it is not a wait for the staged set
+                block = []
+                for nxt in body[ln + 1:]:
+                    if nxt.strip().startswith(";;#ASMEND"):
+                        break
+                    block.append(nxt)
+                is_barrier = any("s_barrier" in b for b in block)
                 continue
             if t.startswith(";;#ASMEND"):
                 in_asm = False
@@ -45,7 +53,7 @@ def audit_text(asm: str):
                     dst = t.split()[1].rstrip(",")
                     for r in regs_of(dst):
                         inflight[r] = ln
-                elif "s_waitcnt" in t and "vmcnt" in t:
+                elif "s_waitcnt" in t and "vmcnt" in t and not is_barrier:
                     inflight.clear()          # the kernels' waits name every staged register of the set
                 continue
             if inflight:
