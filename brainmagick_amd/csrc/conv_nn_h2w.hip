@@ -529,14 +529,22 @@ extern "C" long bm_packed_weight_bytes_h2(int G, int M, int Cin, int KS) {
 
 // One workgroup per (group, padded row): row maximum -> power-of-two scale -> the row's 16-byte slots of both
 // planes (zeros for padded rows / channels) and its inverse scale.
-__global__ __launch_bounds__(128) void pack_weights_h2_kernel(const float* __restrict__ src,
-                                                              unsigned short* __restrict__ dst,
-                                                              float* __restrict__ wscale, int M, int Cin, int KS,
-                                                              long sg, long sm, long sc, long sj, int flip, int Mpad,
-                                                              int nchunk, const float* alpha_ptr) {
-    __shared__ float red[2];
-    const int m = blockIdx.x % Mpad, g = blockIdx.x / Mpad;
-    const float alpha = alpha_ptr ? *alpha_ptr : 1.f;
+struct PackH2Job {
+    const float* src;
+    unsigned short* dst;
+    float* wscale;
+    const float* alpha;
+    long sg, sm, sc, sj;
+    int M, Cin, KS, flip, Mpad, nchunk;
+    int block0, nblocks;      // workgroups [block0, block0 + nblocks) of a batched launch belong to this job
+};
+
+__device__ __forceinline__ void pack_h2_row(const PackH2Job& jb, int block, float* red) {
+    const float* __restrict__ src = jb.src;
+    const int M = jb.M, Cin = jb.Cin, KS = jb.KS, Mpad = jb.Mpad, nchunk = jb.nchunk, flip = jb.flip;
+    const long sg = jb.sg, sm = jb.sm, sc = jb.sc, sj = jb.sj;
+    const int m = block % Mpad, g = block / Mpad;
+    const float alpha = jb.alpha ? *jb.alpha : 1.f;
     const int nk = Cin * KS;
     float mx = 0.f;
     if (m < M)
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(128) void pack_weights_h2_kernel(const float* __res
     __syncthreads();
     float s, inv;
     h2_scale_from_amax(fmaxf(red[0], red[1]), s, inv);
-    if (threadIdx.x == 0) wscale[(long)g * Mpad + m] = inv;
+    if (threadIdx.x == 0) jb.wscale[(long)g * Mpad + m] = inv;
     // slot index inside this row: (chunk, tap, group) -> 8 channels
     const int nslots = nchunk * KS * 4;
     const long plane_stride = (long)4 * Mpad * 8;           // f16 elements of one plane of one (chunk, tap)
@@ -573,23 +581,73 @@ __global__ __launch_bounds__(128) void pack_weights_h2_kernel(const float* __res
             lo[e8] = __builtin_bit_cast(unsigned short, l);
         }
         const long stage = ((long)g * nchunk + chunk) * KS + j;
-        unsigned short* base = dst + stage * 2 * plane_stride + ((long)kg * Mpad + m) * 8;
+        unsigned short* base = jb.dst + stage * 2 * plane_stride + ((long)kg * Mpad + m) * 8;
         *reinterpret_cast<uint4*>(base) = *reinterpret_cast<const uint4*>(hi);
         *reinterpret_cast<uint4*>(base + plane_stride) = *reinterpret_cast<const uint4*>(lo);
     }
 }
 
-extern "C" int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
-                                  long sc, long sj, int flip, const float* alpha_ptr, void* stream) {
+__global__ __launch_bounds__(128) void pack_weights_h2_kernel(PackH2Job jb) {
+    __shared__ float red[2];
+    pack_h2_row(jb, blockIdx.x, red);
+}
+
+// every weight tensor of a model in ONE launch: `jobs` (device memory) sorted by block0
+__global__ __launch_bounds__(128) void pack_weights_h2_batch_kernel(const PackH2Job* __restrict__ jobs, int njobs) {
+    __shared__ float red[2];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                   // last job with block0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackH2Job jb = jobs[lo];
+    pack_h2_row(jb, blockIdx.x - jb.block0, red);
+}
+
+static int pack_h2_fill(PackH2Job& jb, const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
+                        long sc, long sj, int flip, const float* alpha_ptr) {
     BM_REQUIRE(src && dst, "pack_weights_h2: null pointer");
     BM_REQUIRE(G > 0 && M > 0 && Cin > 0 && KS > 0, "pack_weights_h2: bad dims");
-    const int Mpad = bm_conv_h2_mpad(M);
-    const int nchunk = cdiv(Cin, 32);
-    const long f16_elems = (long)G * nchunk * KS * 2 * 4 * Mpad * 8;
-    float* wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + f16_elems * 2);
-    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3((unsigned)(G * Mpad)), dim3(128), 0, (hipStream_t)stream, src,
-                       (unsigned short*)dst, wscale, M, Cin, KS, sg, sm, sc, sj, flip, Mpad, nchunk, alpha_ptr);
+    jb.Mpad = bm_conv_h2_mpad(M);
+    jb.nchunk = cdiv(Cin, 32);
+    const long f16_elems = (long)G * jb.nchunk * KS * 2 * 4 * jb.Mpad * 8;
+    jb.src = src; jb.dst = (unsigned short*)dst;
+    jb.wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + f16_elems * 2);
+    jb.alpha = alpha_ptr;
+    jb.sg = sg; jb.sm = sm; jb.sc = sc; jb.sj = sj;
+    jb.M = M; jb.Cin = Cin; jb.KS = KS; jb.flip = flip;
+    jb.block0 = 0; jb.nblocks = G * jb.Mpad;
+    return BM_OK;
+}
+
+extern "C" int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
+                                  long sc, long sj, int flip, const float* alpha_ptr, void* stream) {
+    PackH2Job jb;
+    if (int rc = pack_h2_fill(jb, src, dst, G, M, Cin, KS, sg, sm, sc, sj, flip, alpha_ptr)) return rc;
+    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3((unsigned)jb.nblocks), dim3(128), 0, (hipStream_t)stream, jb);
     return bm_check_launch("pack_weights_h2");
+}
+
+// Batched packing.  The host builds a table of jobs (bm_pack_h2_job_bytes() bytes each, filled by
+// bm_pack_h2_job_fill, which returns the job's workgroup count or a negative error), copies it to the device
+// once, and re-packs every weight tensor of the model with one launch per optimizer step.
+extern "C" int bm_pack_h2_job_bytes() { return (int)sizeof(PackH2Job); }
+
+extern "C" int bm_pack_h2_job_fill(void* job, const float* src, void* dst, int G, int M, int Cin, int KS, long sg,
+                                   long sm, long sc, long sj, int flip, const float* alpha_ptr, int block0) {
+    if (!job) return -1;
+    PackH2Job jb;
+    if (pack_h2_fill(jb, src, dst, G, M, Cin, KS, sg, sm, sc, sj, flip, alpha_ptr)) return -1;
+    jb.block0 = block0;
+    memcpy(job, &jb, sizeof(jb));
+    return jb.nblocks;
+}
+
+extern "C" int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
+    BM_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_weights_h2_batch: bad arguments");
+    hipLaunchKernelGGL(pack_weights_h2_batch_kernel, dim3((unsigned)total_blocks), dim3(128), 0, (hipStream_t)stream,
+                       (const PackH2Job*)jobs_dev, njobs);
+    return bm_check_launch("pack_weights_h2_batch");
 }
 
 // max |x[i]| as <= 256 per-workgroup partial maxima (ws) folded by bm_amax_finalize into the slot `out`

@@ -279,6 +279,11 @@ def sync_flat_gradients(optimizer, average: bool = True) -> tp.Optional[tp.Tuple
     return shard_bounds(optimizer.flat_grad.numel(), world_size(), rank())
 
 
+def hip_ops_weights_changed():
+    from . import hip_ops
+    hip_ops.weights_changed()
+
+
 def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None) -> None:
     """``flashy.distrib.sync_model`` + ``optimizer.step()`` (bm/solver.py:386-387) on the flat bucket:
     reduce-scatter(grads) -> Adam on the own shard (mean over ranks via grad_scale) -> all-gather
@@ -289,6 +294,7 @@ def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None) -> None
     shard = sync_flat_gradients(optimizer)
     optimizer.step(shard=shard, grad_scale=1.0 / world_size())
     _comm.all_gather_shards(optimizer.flat_param)
+    hip_ops_weights_changed()               # parameters were written through raw pointers: packed copies are stale
     if buffers is not None:
         buffers.average()
 

@@ -63,15 +63,22 @@ class KernelTimer:
         return out
 
     def summary(self) -> tp.Dict[str, tp.Dict[str, float]]:
-        """name -> {launches, avg_ms, flops_per_launch}; call after a device synchronize."""
-        agg: tp.Dict[str, tp.List[float]] = {}
+        """name -> {launches, avg_ms, median_ms, max_ms, outliers, flops_per_launch}; call after a device
+        synchronize.  ``avg_ms`` is the mean over the launches whose duration is within 20x the label's median: an
+        event pair also measures whatever keeps the queue from reaching the kernel (a host stall between the two
+        records shows up as a launch of many milliseconds); the dropped samples are counted in ``outliers``."""
+        samples: tp.Dict[str, tp.List[float]] = {}
+        flops_sum: tp.Dict[str, float] = {}
         for name, flops, start, end in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += start.elapsed_time(end)
-            a[2] += flops
-        return {k: dict(launches=v[0], avg_ms=v[1] / v[0], flops_per_launch=v[2] / v[0])
-                for k, v in agg.items()}
+            samples.setdefault(name, []).append(start.elapsed_time(end))
+            flops_sum[name] = flops_sum.get(name, 0.0) + flops
+        out = {}
+        for name, v in samples.items():
+            med = sorted(v)[len(v) // 2]
+            kept = [t for t in v if t <= 20.0 * med]
+            out[name] = dict(launches=len(v), avg_ms=sum(kept) / len(kept), median_ms=med, max_ms=max(v),
+                             outliers=len(v) - len(kept), flops_per_launch=flops_sum[name] / len(v))
+        return out
 
 
 _timer: tp.Optional[KernelTimer] = None
@@ -168,6 +175,82 @@ def _slot_args(slot):
     return (_p(slot), _p(_amax_ws(slot.device)) if slot is not None else None)
 
 
+# ------------------------------------------------------------------------------------------------
+# Packed parameters.  A model's weights change once per optimizer step, so in "f16x2" mode the packed form of
+# every PARAMETER (leaf tensor that requires grad) that the convs ask for lives in a persistent buffer, and all
+# of them are refreshed together by one launch (bm_pack_weights_h2_batch) the first time one is asked for after
+# the parameters changed -- instead of one small launch per conv, forward and backward.  "Changed" = the
+# library's own writers said so (weights_changed(): FlatAdam.step, the data-parallel gathers) or the tensor's
+# autograd version moved (load_state_dict, in-place edits); evaluation never re-packs.
+_BATCH_PACK = _os.environ.get("BM_BATCH_PACK", "1") == "1"
+_weights_epoch = 0
+pack_launches = 0            # launches of either packing kernel (tests / bench bookkeeping)
+
+
+def weights_changed():
+    """Called by every library routine that writes parameters through raw pointers."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+class _PackPlan:
+    MAX_JOBS = 512           # e.g. many models in one test session: start over rather than grow without bound
+
+    def __init__(self, device):
+        self.device = device
+        self.entries: tp.Dict[tuple, dict] = {}
+        self.table: tp.Optional[torch.Tensor] = None
+        self.total_blocks = 0
+
+    def get(self, src: torch.Tensor, geom: tuple) -> torch.Tensor:
+        key = (src.data_ptr(),) + geom
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= self.MAX_JOBS:
+                self.entries.clear()
+            G, M, Cin, KS = geom[:4]
+            dst = torch.empty(lib().bm_packed_weight_bytes_h2(G, M, Cin, KS), device=src.device, dtype=torch.uint8)
+            dst._bm_mode = "f16x2"
+            dst._bm_groups = G
+            # `src` is kept alive: the batched launch reads it through its raw pointer
+            e = self.entries[key] = dict(src=src, geom=geom, dst=dst, stamp=None)
+            self.table = None
+        if e["stamp"] != (_weights_epoch, src._version):
+            self.refresh()
+        return e["dst"]
+
+    def refresh(self):
+        global pack_launches
+        ents = list(self.entries.values())
+        if self.table is None:
+            nb = lib().bm_pack_h2_job_bytes()
+            host = ctypes.create_string_buffer(nb * len(ents))
+            block0 = 0
+            for i, e in enumerate(ents):
+                n = lib().bm_pack_h2_job_fill(ctypes.c_void_p(ctypes.addressof(host) + i * nb), _p(e["src"]),
+                                              _p(e["dst"]), *e["geom"], None, block0)
+                if n < 0:
+                    raise BmHipError("bm_pack_h2_job_fill: bad arguments %r" % (e["geom"],))
+                block0 += n
+            self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+            self.total_blocks = block0
+        check(lib().bm_pack_weights_h2_batch(_p(self.table), len(ents), self.total_blocks, _stream()),
+              "bm_pack_weights_h2_batch")
+        pack_launches += 1
+        for e in ents:
+            e["stamp"] = (_weights_epoch, e["src"]._version)
+
+
+_pack_plans: tp.Dict[tp.Tuple[str, int], _PackPlan] = {}
+
+
+def _pack_plan(device) -> _PackPlan:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _pack_plans:
+        _pack_plans[key] = _PackPlan(torch.device(*key))
+    return _pack_plans[key]
+
+
 def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, sm: int, sc: int,
                  sj: int, flip: bool = False, alpha: tp.Optional[torch.Tensor] = None,
                  shape: tp.Optional[tp.Tuple[int, int]] = None) -> torch.Tensor:
@@ -177,10 +260,14 @@ def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, 
     mode = _compute_dtype
     if mode == "f16x2":
         if shape is not None and lib().bm_conv_h2_covers(Cin, M, shape[0], KS, shape[1]):
+            if alpha is None and src.requires_grad and src.is_leaf and _BATCH_PACK:
+                return _pack_plan(src.device).get(src, (G, M, Cin, KS, sg, sm, sc, sj, int(flip)))
             nbytes = lib().bm_packed_weight_bytes_h2(G, M, Cin, KS)
             dst = torch.empty(nbytes, device=src.device, dtype=torch.uint8)
             check(lib().bm_pack_weights_h2(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
                                            _p(_opt(alpha, "alpha")), _stream()), "bm_pack_weights_h2")
+            global pack_launches
+            pack_launches += 1
             dst._bm_mode = "f16x2"
             dst._bm_groups = G
             return dst
@@ -661,3 +748,4 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: flo
         _req(t, f"adam_step.{n}")
     check(lib().bm_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), step,
                              lr, beta1, beta2, eps, grad_scale, _stream()), "bm_adam_step")
+    weights_changed()

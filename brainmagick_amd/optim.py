@@ -84,10 +84,38 @@ class FlatAdam(torch.optim.Optimizer):
 
     # -- torch.optim API used by the Solver (bm/solver.py:384-387) --
     def zero_grad(self, set_to_none: bool = False):
+        """``set_to_none=False`` (torch semantics): the bucket is zeroed and every ``p.grad`` is its view of the
+        bucket, so autograd accumulates in place (one add per parameter).  ``set_to_none=True``: ``p.grad = None``;
+        autograd then hands over its gradient tensors and ``collect_grads()`` moves them into the bucket with one
+        multi-tensor copy -- what the Solver does every step."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
         self.flat_grad.zero_()
+        self._attach_views()
+
+    def _attach_views(self):
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def collect_grads(self):
+        """After ``zero_grad(set_to_none=True)`` + backward: copy the gradients autograd produced into the flat
+        bucket (parameters that received none read as zero) and make every ``p.grad`` the bucket view again."""
+        views, grads = [], []
+        for p, off in zip(self.params, self.offsets):
+            view = self.flat_grad[off:off + p.numel()].view(p.shape)
+            g = p.grad
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() != view.data_ptr():
+                views.append(view)
+                grads.append(g if g.dtype == torch.float32 else g.float())
+            p.grad = view
+        if views:
+            torch._foreach_copy_(views, grads)
 
     @torch.no_grad()
     def step(self, closure=None, shard: tp.Optional[tp.Tuple[int, int]] = None,
@@ -97,6 +125,7 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.collect_grads()                # no-op when every p.grad already is its bucket view
         self.step_count += 1
         self._step_tensor.fill_(float(self.step_count))
         lo, hi = shard if shard is not None else (0, self.padded)

@@ -122,8 +122,9 @@ class Solver:
         loss = self.loss(estimate, output, features_mask, target_offset=target_offset)
         # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path
         # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        self.optimizer.collect_grads()      # one multi-tensor copy instead of an accumulate-add per parameter
         distrib.sharded_step(self.optimizer, self._buffers)
         return loss.detach()
 

@@ -1,13 +1,26 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_t; mkdir -p $R/gpurun_out
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_t -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip > $R/gpurun_out/prof_t.log 2>&1
-cd $R
-python - <<'PY'
-import csv,glob
-f=glob.glob('gpurun_out/prof_t/**/*kernel_stats.csv',recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:28]:
-    print(r['Name'][:80], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['MinNs'], r['MaxNs'])
+cd ${GRAFT_REPO_ROOT:-.}; mkdir -p gpurun_out
+python - <<'PY' 2>&1 | tail -30
+import torch, bench
+from brainmagick_amd import hip_ops as H, synthetic
+from brainmagick_amd.models import SimpleConv
+from brainmagick_amd.solver import Solver
+c = synthetic.CONFIGS["cfg2"]
+model = SimpleConv(in_channels={"meg": c["C"]}, out_channels=c["F"], hidden={"meg": 320}, n_subjects=c["S"], **bench.CLIP_CONV)
+solver = Solver(model, device="cuda:0")
+stream = bench.BatchStream("cfg2", 256, 0, torch.device("cuda:0"))
+for _ in range(2): solver.train_step(stream.next())
+orig = H._PackPlan.get
+def get(self, src, geom):
+    key = (src.data_ptr(),) + geom
+    e = self.entries.get(key)
+    if e is None:
+        print("NEW", geom, src.shape, src.requires_grad, src.is_leaf)
+    elif e["stamp"] != (H._weights_epoch, src._version):
+        print("STALE", geom[:4], "stamp", e["stamp"], "now", (H._weights_epoch, src._version), "reg ver", e["src"]._version, src is e["src"])
+    return orig(self, src, geom)
+H._PackPlan.get = get
+for _ in range(2):
+    print("--- step")
+    solver.train_step(stream.next())
 PY
-find gpurun_out/prof_t -name "*kernel_trace.csv" -size +30M -delete

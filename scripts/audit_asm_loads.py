@@ -53,8 +53,8 @@ def audit_text(asm: str):
                     dst = t.split()[1].rstrip(",")
                     for r in regs_of(dst):
                         inflight[r] = ln
-                elif "s_waitcnt" in t and "vmcnt" in t and not is_barrier:
-                    inflight.clear()          # the kernels' waits name every staged register of the set
+                elif "s_waitcnt" in t and "vmcnt" in t and (not is_barrier or "vmcnt(0)" in t):
+                    inflight.clear()          # (a barrier statement only counts when it drains the queue)          # the kernels' waits name every staged register of the set
                 continue
             if inflight:
                 hit = regs_of(t) & set(inflight)

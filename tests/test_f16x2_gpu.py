@@ -262,3 +262,41 @@ def test_training_step_needs_few_standalone_amax_passes(h2_mode, H):
     scans = H.amax_scans - before
     print("stand-alone amax passes per training step:", scans)
     assert scans <= 6, scans       # the model input, the candidates and ClipLoss' operands
+
+
+def test_parameters_are_packed_once_per_step(h2_mode, H):
+    """All conv parameters of a model are re-packed by ONE launch per optimizer step (hip_ops._PackPlan); edits
+    through torch (version counter) and through the library (weights_changed) both invalidate the packed copies."""
+    from brainmagick_amd import synthetic
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.solver import Solver
+    from oracle import bm_oracle as O
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=32, merger_channels=24, initial_linear=24, merger_dropout=0.0)
+    torch.manual_seed(0)
+    # wide enough (T > 128, M >= 96) for the f16x2 conv kernel, whose packed layout the plan manages
+    model = SimpleConv(in_channels={"meg": 20}, out_channels=12, hidden={"meg": 96}, n_subjects=3, **cfg)
+    solver = Solver(model)
+    sb = synthetic.make_batch(4, 20, 160, 12, 3, seed=5)
+    solver.train_step(sb)
+    n0 = H.pack_launches
+    losses = [float(solver.train_step(sb)) for _ in range(3)]
+    assert H.pack_launches - n0 == 3, H.pack_launches - n0
+    # evaluation after the last step: one refresh (the step changed the weights), then none
+    solver.eval_step(sb)
+    n1 = H.pack_launches
+    e1 = float(solver.eval_step(sb))
+    assert H.pack_launches == n1
+    # an in-place edit through torch is seen (version counter) ...
+    with torch.no_grad():
+        next(p for p in model.parameters() if p.dim() == 3 and p.shape[2] == 3).mul_(1.5)
+    e2 = float(solver.eval_step(sb))
+    assert H.pack_launches == n1 + 1 and e2 != e1
+    # ... and the batched packing gives the same numbers as per-conv packing
+    H._BATCH_PACK = False
+    try:
+        e3 = float(solver.eval_step(sb))
+    finally:
+        H._BATCH_PACK = True
+    assert e3 == e2, (e2, e3)
+    assert all(math.isfinite(v) for v in losses)
