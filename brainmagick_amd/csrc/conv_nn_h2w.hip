@@ -187,6 +187,9 @@ extern "C" int bm_debug_trace_read_conv(unsigned* out) {
 template <int KS, int MW>
 __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     const ConvNNArgs& a = args.c;
+#ifdef HG_TRACE
+    const unsigned t_kernel0 = (unsigned)__builtin_readcyclecounter();
+#endif
     constexpr int NW = 3;
     constexpr int HBM = 64 * MW;                      // rows of the workgroup tile
     constexpr int HASLAB = 2 * 2 * HBM;               // 16-byte slots of one A buffer
@@ -332,6 +335,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
 #ifdef HG_TRACE
     unsigned tr[8], tacc[3][8];
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) tacc[i][k] = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned t_loop0 = (unsigned)__builtin_readcyclecounter();
 #endif
     for (int c16 = 0; c16 < n16; ++c16) {
         const int xbuf = c16 & 1;
@@ -415,6 +420,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
         });
     }
 #ifdef HG_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned t_loop1 = (unsigned)__builtin_readcyclecounter();
     if (blockIdx.x < 64 && lane == 0)
         for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) ch_trace_buf[((blockIdx.x * 4 + wave) * 3 + i) * 8 + k] = tacc[i][k];
 #endif
@@ -479,6 +486,15 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
                                                    n0 + wn * (NW * 32) + nl, 0.f);
         bm_publish_amax(amx, args.y_amax_ws, smem + 4 * HBM);
     }
+#ifdef HG_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile's stores have left the CU
+    if (blockIdx.x < 64 && lane == 0) {
+        unsigned* o = ch_trace_buf + ((blockIdx.x * 4 + wave) * 3) * 8;
+        o[5] = t_loop0 - t_kernel0;
+        o[6] = (unsigned)__builtin_readcyclecounter() - t_loop1;
+        o[8 + 5] = t_loop1 - t_loop0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -19,156 +19,115 @@ from .. import hip_ops as H
 
 
 class SimpleConv(nn.Module):
-    def __init__(self,
-                 # Channels
-                 in_channels: tp.Dict[str, int],
-                 out_channels: int,
-                 hidden: tp.Dict[str, int],
-                 # Overall structure
-                 depth: int = 4,
-                 concatenate: bool = False,  # concatenate the inputs
-                 linear_out: bool = False,
-                 complex_out: bool = False,
-                 # Conv layer
-                 kernel_size: int = 5,
-                 growth: float = 1.,
-                 dilation_growth: int = 2,
-                 dilation_period: tp.Optional[int] = None,
-                 skip: bool = False,
-                 post_skip: bool = False,
-                 scale: tp.Optional[float] = None,
-                 rewrite: bool = False,
-                 groups: int = 1,
-                 glu: int = 0,
-                 glu_context: int = 0,
-                 glu_glu: bool = True,
-                 gelu: bool = False,
-                 # Dual path RNN
-                 dual_path: int = 0,
-                 # Dropouts, BN, activations
-                 conv_dropout: float = 0.0,
-                 dropout_input: float = 0.0,
-                 batch_norm: bool = False,
-                 relu_leakiness: float = 0.0,
-                 # Subject specific settings
-                 n_subjects: int = 200,
-                 subject_dim: int = 64,
-                 subject_layers: bool = False,
-                 subject_layers_dim: str = "input",  # or hidden
-                 subject_layers_id: bool = False,
-                 embedding_scale: float = 1.0,
-                 # stft transform
-                 n_fft: tp.Optional[int] = None,
-                 fft_complex: bool = True,
-                 # Attention multi-dataset support
-                 merger: bool = False,
-                 merger_pos_dim: int = 256,
-                 merger_channels: int = 270,
-                 merger_dropout: float = 0.2,
-                 merger_penalty: float = 0.,
-                 merger_per_subject: bool = False,
-                 dropout: float = 0.,
-                 dropout_rescale: bool = True,
-                 initial_linear: int = 0,
-                 initial_depth: int = 1,
-                 initial_nonlin: bool = False,
-                 subsample_meg_channels: int = 0,
-                 ):
+    """Constructor keywords, defaults, sub-module names and ``state_dict`` keys are the reference's
+    (bm/models/simpleconv.py:23-77): ``bm/train.py:84-86`` passes ``**args.simpleconv`` and reference
+    checkpoints load with ``strict=True``.  Keywords are grouped here by what this implementation does with
+    them: built on the HIP path / accepted for signature compatibility / rejected."""
+
+    def __init__(self, in_channels: tp.Dict[str, int], out_channels: int, hidden: tp.Dict[str, int],
+                 depth: int = 4, concatenate: bool = False, linear_out: bool = False,
+                 complex_out: bool = False, kernel_size: int = 5, growth: float = 1.,
+                 dilation_growth: int = 2, dilation_period: tp.Optional[int] = None, skip: bool = False,
+                 post_skip: bool = False, scale: tp.Optional[float] = None, rewrite: bool = False,
+                 groups: int = 1, glu: int = 0, glu_context: int = 0, glu_glu: bool = True,
+                 gelu: bool = False, dual_path: int = 0, conv_dropout: float = 0.0,
+                 dropout_input: float = 0.0, batch_norm: bool = False, relu_leakiness: float = 0.0,
+                 n_subjects: int = 200, subject_dim: int = 64, subject_layers: bool = False,
+                 subject_layers_dim: str = "input", subject_layers_id: bool = False,
+                 embedding_scale: float = 1.0, n_fft: tp.Optional[int] = None, fft_complex: bool = True,
+                 merger: bool = False, merger_pos_dim: int = 256, merger_channels: int = 270,
+                 merger_dropout: float = 0.2, merger_penalty: float = 0., merger_per_subject: bool = False,
+                 dropout: float = 0., dropout_rescale: bool = True, initial_linear: int = 0,
+                 initial_depth: int = 1, initial_nonlin: bool = False, subsample_meg_channels: int = 0):
         super().__init__()
-        if set(in_channels.keys()) != set(hidden.keys()):
+        if set(in_channels) != set(hidden):
             raise ValueError("Channels and hidden keys must match "
                              f"({set(in_channels.keys())} and {set(hidden.keys())})")
-        off_path = dict(concatenate=concatenate, dual_path=bool(dual_path), n_fft=n_fft is not None,
-                        dropout=dropout > 0., multi_input=set(in_channels) != {"meg"})
-        bad = [k for k, v in off_path.items() if v]
-        if bad:
+        rejected = [name for name, used in dict(
+            concatenate=concatenate, dual_path=bool(dual_path), n_fft=n_fft is not None,
+            dropout=dropout > 0., multi_input=set(in_channels) != {"meg"}).items() if used]
+        if rejected:
             raise NotImplementedError(
-                f"SimpleConv options {bad} are outside the MI355X hot path (STFT / DualPathRNN / "
+                f"SimpleConv options {rejected} are outside the MI355X hot path (STFT / DualPathRNN / "
                 "ChannelDropout / multi-input are unused by the paper's grids, SURVEY.md §2.2)")
-        self._concatenate = concatenate
+        if kernel_size % 2 != 1:
+            raise AssertionError("For padding to work, this must be verified")       # reference message
+        if linear_out and complex_out:
+            raise AssertionError("linear_out and complex_out are exclusive")
         self.out_channels = out_channels
         activation = make_activation(gelu, relu_leakiness)
-        assert kernel_size % 2 == 1, "For padding to work, this must be verified"
 
-        self.merger = None
-        self.dropout = None
+        width = in_channels["meg"]
         self.subsampled_meg_channels: tp.Optional[list] = None
         if subsample_meg_channels:
-            assert 'meg' in in_channels
-            indexes = list(range(in_channels['meg']))
-            rng = random.Random(1234)
-            rng.shuffle(indexes)
-            self.subsampled_meg_channels = indexes[:subsample_meg_channels]
-            keep = torch.zeros(1, in_channels['meg'], 1)
-            keep[:, self.subsampled_meg_channels] = 1.
-            self.register_buffer("_channel_keep", keep, persistent=False)
+            self._subsample(width, subsample_meg_channels)
+        width = self._build_front_end(
+            width, activation, hidden["meg"], n_subjects,
+            merger=dict(on=merger, channels=merger_channels, pos_dim=merger_pos_dim, dropout=merger_dropout,
+                        penalty=merger_penalty, per_subject=merger_per_subject),
+            linear=dict(width=initial_linear, depth=initial_depth, nonlin=initial_nonlin),
+            subject=dict(layers=subject_layers, where=subject_layers_dim, init_id=subject_layers_id,
+                         emb_dim=subject_dim, emb_scale=embedding_scale))
 
-        self.initial_linear = None
-        if merger:
-            self.merger = ChannelMerger(
-                merger_channels, pos_dim=merger_pos_dim, dropout=merger_dropout,
-                usage_penalty=merger_penalty, n_subjects=n_subjects, per_subject=merger_per_subject)
-            in_channels["meg"] = merger_channels
-
-        if initial_linear:
-            init = [nn.Conv1d(in_channels["meg"], initial_linear, 1)]
-            for _ in range(initial_depth - 1):
-                init += [activation(), nn.Conv1d(initial_linear, initial_linear, 1)]
-            if initial_nonlin:
-                init += [activation()]
-            self.initial_linear = nn.Sequential(*init)
-            in_channels["meg"] = initial_linear
-
-        self.subject_layers = None
-        if subject_layers:
-            assert "meg" in in_channels
-            meg_dim = in_channels["meg"]
-            dim = {"hidden": hidden["meg"], "input": meg_dim}[subject_layers_dim]
-            self.subject_layers = SubjectLayers(meg_dim, dim, n_subjects, subject_layers_id)
-            in_channels["meg"] = dim
-
-        self.stft = None
-        self.subject_embedding = None
-        if subject_dim:
-            self.subject_embedding = ScaledEmbedding(n_subjects, subject_dim, embedding_scale)
-            in_channels["meg"] += subject_dim
-
-        # sequence of channel sizes of the conv stack
-        sizes = {}
-        for name in in_channels:
-            sizes[name] = [in_channels[name]]
-            sizes[name] += [int(round(hidden[name] * growth ** k)) for k in range(depth)]
-
-        params: tp.Dict[str, tp.Any]
-        params = dict(kernel=kernel_size, stride=1,
-                      leakiness=relu_leakiness, dropout=conv_dropout, dropout_input=dropout_input,
-                      batch_norm=batch_norm, dilation_growth=dilation_growth, groups=groups,
-                      dilation_period=dilation_period, skip=skip, post_skip=post_skip, scale=scale,
-                      rewrite=rewrite, glu=glu, glu_context=glu_context, glu_glu=glu_glu,
-                      activation=activation)
-
-        final_channels = sum([x[-1] for x in sizes.values()])
-        self.dual_path = None
-        self.final = None
+        # conv stack and head; without a head the last conv of the stack produces the output channels
+        widths = [width] + [int(round(hidden["meg"] * growth ** k)) for k in range(depth)]
+        stack_kw = dict(kernel=kernel_size, stride=1, leakiness=relu_leakiness, dropout=conv_dropout,
+                        dropout_input=dropout_input, batch_norm=batch_norm, dilation_growth=dilation_growth,
+                        groups=groups, dilation_period=dilation_period, skip=skip, post_skip=post_skip,
+                        scale=scale, rewrite=rewrite, glu=glu, glu_context=glu_context, glu_glu=glu_glu,
+                        activation=activation)
+        top = widths[-1]
         if linear_out:
-            assert not complex_out
-            self.final = nn.ConvTranspose1d(final_channels, out_channels, 1, 1, 0)
+            self.final = nn.ConvTranspose1d(top, out_channels, 1, 1, 0)
         elif complex_out:
-            self.final = nn.Sequential(
-                nn.Conv1d(final_channels, 2 * final_channels, 1),
-                activation(),
-                nn.ConvTranspose1d(2 * final_channels, out_channels, 1, 1, 0))
+            self.final = nn.Sequential(nn.Conv1d(top, 2 * top, 1), activation(),
+                                       nn.ConvTranspose1d(2 * top, out_channels, 1, 1, 0))
         else:
-            assert len(sizes) == 1, "if no linear_out, there must be a single branch."
-            params['activation_on_last'] = False
-            list(sizes.values())[0][-1] = out_channels
+            self.final = None
+            stack_kw["activation_on_last"] = False
+            widths[-1] = out_channels
+        self.encoders = nn.ModuleDict({"meg": ConvSequence(widths, **stack_kw)})
 
-        self.encoders = nn.ModuleDict({name: ConvSequence(channels, **params)
-                                       for name, channels in sizes.items()})
+    def _subsample(self, n_sensors: int, keep_n: int):
+        """`subsample_meg_channels`: a fixed pseudo-random subset of sensors (seed 1234, simpleconv.py:95-100)
+        survives, as a constant 0/1 mask applied on the device."""
+        order = list(range(n_sensors))
+        random.Random(1234).shuffle(order)
+        self.subsampled_meg_channels = order[:keep_n]
+        keep = torch.zeros(1, n_sensors, 1)
+        keep[:, self.subsampled_meg_channels] = 1.
+        self.register_buffer("_channel_keep", keep, persistent=False)
+
+    def _build_front_end(self, width: int, activation, hidden: int, n_subjects: int, merger: dict,
+                         linear: dict, subject: dict) -> int:
+        """Spatial attention -> 1x1 convs -> per-subject linear map -> subject embedding
+        (simpleconv.py:102-135); returns the channel count handed to the conv stack."""
+        self.merger = self.initial_linear = self.subject_layers = self.subject_embedding = None
+        if merger["on"]:
+            self.merger = ChannelMerger(merger["channels"], pos_dim=merger["pos_dim"], dropout=merger["dropout"],
+                                        usage_penalty=merger["penalty"], n_subjects=n_subjects,
+                                        per_subject=merger["per_subject"])
+            width = merger["channels"]
+        if linear["width"]:
+            layers: tp.List[nn.Module] = [nn.Conv1d(width, linear["width"], 1)]
+            for _ in range(linear["depth"] - 1):
+                layers += [activation(), nn.Conv1d(linear["width"], linear["width"], 1)]
+            if linear["nonlin"]:
+                layers.append(activation())
+            self.initial_linear = nn.Sequential(*layers)
+            width = linear["width"]
+        if subject["layers"]:
+            out = {"hidden": hidden, "input": width}[subject["where"]]
+            self.subject_layers = SubjectLayers(width, out, n_subjects, subject["init_id"])
+            width = out
+        if subject["emb_dim"]:
+            self.subject_embedding = ScaledEmbedding(n_subjects, subject["emb_dim"], subject["emb_scale"])
+            width += subject["emb_dim"]
+        return width
 
     def forward(self, inputs, batch):
         subjects = batch.subject_index
-        length = next(iter(inputs.values())).shape[-1]  # length of any of the inputs
+        length = inputs["meg"].shape[-1]
         x = inputs["meg"]
         if not x.is_cuda:
             raise RuntimeError("brainmagick_amd.SimpleConv runs on the MI355X HIP path only; got a "

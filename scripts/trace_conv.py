@@ -26,7 +26,8 @@ for Cin, M, KS, dil in [(320, 320, 3, 2), (320, 640, 1, 1)]:
     rc = H.lib().bm_debug_trace_read_conv(out)
     assert rc == 0, rc
     tr = torch.tensor(list(out), dtype=torch.float64).view(64, 4, 3, 8)
-    print(f"conv Cin={Cin} M={M} KS={KS}")
+    print(f"conv Cin={Cin} M={M} KS={KS}: per tile, cycles: prologue {tr[..., 0, 5].mean().item():.0f}, main loop "
+          f"{tr[..., 1, 5].mean().item():.0f}, last term + epilogue (stores drained) {tr[..., 0, 6].mean().item():.0f}")
     for j in range(KS):
         n = tr[..., j, 7].clamp(min=1)
         per = tr[..., j, :5] / n[..., None]
