@@ -241,7 +241,15 @@ def init(backend: tp.Optional[str] = None):
         backend = "rccl" if torch.cuda.is_available() else "gloo"
         if backend == "rccl" and os.environ.get("BM_COMM", "") == "torch":
             backend = "nccl"
-    _comm = _RcclComm() if backend == "rccl" else _TorchComm(backend)
+    if backend == "rccl":
+        try:
+            _comm = _RcclComm()
+        except Exception as exc:      # librccl not loadable / no communicator: same on every rank of a node
+            import warnings
+            warnings.warn(f"RCCL through the C-ABI is unavailable ({exc}); using torch.distributed's binding")
+            _comm = _TorchComm("nccl")
+    else:
+        _comm = _TorchComm(backend)
 
 
 def shutdown():
