@@ -695,3 +695,34 @@ def test_deep_mel_shape_like_reference():
     out = model(features)
     assert len(model.sequence) == 5
     assert out.shape == (features.shape[0], 2, features.shape[2])
+
+
+def test_gradients_collected_by_copy_equal_accumulated_ones():
+    """FlatAdam.zero_grad(set_to_none=True) + collect_grads() (what Solver.train_step does: autograd hands its
+    gradient tensors over, one multi-tensor copy moves them into the flat bucket) gives bit-identical buckets to
+    torch-style accumulation into the bucket views; parameters that got no gradient read as zero."""
+    from brainmagick_amd.solver import Solver
+    model, _ = _small_model(merger_dropout=0.0)
+    solver = Solver(model)
+    opt = solver.optimizer
+    sb = synthetic.make_batch(4, 20, 40, 10, 3, seed=8)
+
+    def loss_of():
+        estimate, output, mask, _ = solver._process_batch(sb, training=True)
+        return solver.loss(estimate, output, mask)
+
+    opt.zero_grad()
+    loss_of().backward()
+    accumulated = opt.flat_grad.clone()
+    opt.flat_grad.fill_(7.0)                                        # stale content must not survive
+    opt.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in opt.params)
+    loss_of().backward()
+    opt.collect_grads()
+    assert torch.equal(opt.flat_grad[:opt.numel], accumulated[:opt.numel])
+    for p, off in zip(opt.params, opt.offsets):
+        assert p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * off
+    # a parameter without a gradient reads as zero
+    opt.zero_grad(set_to_none=True)
+    opt.collect_grads()
+    assert float(opt.flat_grad.abs().max()) == 0.0
