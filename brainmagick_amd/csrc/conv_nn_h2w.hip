@@ -669,29 +669,44 @@ extern "C" int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int tot
 // max |x[i]| as <= 256 per-workgroup partial maxima (ws) folded by bm_amax_finalize into the slot `out`
 // (BM_AMAX_SHARDS floats whose maximum is the answer).  A non-finite input yields a non-finite or NaN-free
 // maximum of the finite part; the non-finite values themselves propagate through the consumer's split.
-__global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x, long n, float* __restrict__ ws) {
+__global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x, long n, float* __restrict__ ws,
+                                                    int* __restrict__ nonfinite) {
     __shared__ float sh[16];
     float mx = 0.f;
+    unsigned top = 0u;                                  // largest |x| bit pattern: >= 0x7f800000 <=> inf / nan seen
     const long n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = x4[i];
         mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+        top = max(max(top, __float_as_uint(v.x) & 0x7fffffffu),
+                  max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu,
+                                                               __float_as_uint(v.w) & 0x7fffffffu)));
     }
     if (blockIdx.x == 0)
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, fabsf(x[i]));
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+            mx = fmaxf(mx, fabsf(x[i]));
+            top = max(top, __float_as_uint(x[i]) & 0x7fffffffu);
+        }
+    if (nonfinite && top >= 0x7f800000u) atomicOr(nonfinite, 1);     // rare: at most one atomic per thread
     bm_publish_amax(mx, ws, sh);
 }
 
-extern "C" int bm_amax(const float* x, long n, float* out, float* ws, void* stream) {
+// `nonfinite_flag` (nullable, device int): set to 1 if x holds an inf or a nan -- the reference's
+// `torch.isfinite(x).all()` asserts (bm/solver.py:258-260) ride on the pass that the f16x2 scale needs anyway.
+extern "C" int bm_amax_checked(const float* x, long n, float* out, float* ws, int* nonfinite_flag, void* stream) {
     BM_REQUIRE(x && out && ws && n >= 0, "amax: bad arguments");
     BM_REQUIRE(((uintptr_t)x & 15) == 0, "amax: x must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     long blocks = (n / 4 + 1023) / 1024;
     blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, x, n, ws);
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, x, n, ws, nonfinite_flag);
     if (int rc = bm_check_launch("amax")) return rc;
     return bm_amax_finalize(ws, (int)blocks, out, s);
+}
+
+extern "C" int bm_amax(const float* x, long n, float* out, float* ws, void* stream) {
+    return bm_amax_checked(x, n, out, ws, nullptr, stream);
 }
 
 template <int KS, int MW>

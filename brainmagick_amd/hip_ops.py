@@ -121,20 +121,23 @@ AMAX_SHARDS = 8       # an amax slot is 8 floats (shards of the atomic maximum, 
 amax_scans = 0        # number of stand-alone amax passes launched (producers that publish their own maximum need none)
 
 
-def amax(x: torch.Tensor) -> torch.Tensor:
+def amax(x: torch.Tensor, nonfinite_flag: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
     """[AMAX_SHARDS] fp32 tensor whose maximum is max |x| (device side, no sync).  Cached on the tensor object together with
     its version counter, so a tensor consumed by several contractions (forward conv, weight gradient) is
-    scanned once and an in-place modification invalidates the cache."""
+    scanned once and an in-place modification invalidates the cache.  ``nonfinite_flag`` (int32 device tensor):
+    element 0 is set to 1 by the same pass if x holds an inf / nan (a cached tensor was checked when it was scanned)."""
     cached = getattr(x, "_bm_amax", None)
-    if cached is not None and cached[0] == x._version and cached[1] == x.data_ptr():
+    if cached is not None and cached[0] == x._version and cached[1] == x.data_ptr() and \
+            (nonfinite_flag is None or cached[3]):
         return cached[2]
     _req(x, "amax.x")
     global amax_scans
     amax_scans += 1
     out = torch.empty(AMAX_SHARDS, device=x.device, dtype=torch.float32)
-    check(lib().bm_amax(_p(x), x.numel(), _p(out), _p(_amax_ws(x.device)), _stream()), "bm_amax")
+    check(lib().bm_amax_checked(_p(x), x.numel(), _p(out), _p(_amax_ws(x.device)),
+                                _p(_opt(nonfinite_flag, "nonfinite_flag", torch.int32)), _stream()), "bm_amax")
     try:
-        x._bm_amax = (x._version, x.data_ptr(), out)
+        x._bm_amax = (x._version, x.data_ptr(), out, nonfinite_flag is not None)
     except Exception:       # tensors that refuse attributes: just do not cache
         pass
     return out
@@ -166,7 +169,7 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
         pool = _amax_pool[t.device] = [torch.empty(4096 * AMAX_SHARDS, device=t.device, dtype=torch.float32), 0]
     slot = pool[0][pool[1]:pool[1] + AMAX_SHARDS]
     pool[1] += AMAX_SHARDS
-    t._bm_amax = (t._version, t.data_ptr(), slot)
+    t._bm_amax = (t._version, t.data_ptr(), slot, False)
     return slot
 
 
@@ -364,7 +367,7 @@ def index_error_flag(device) -> torch.Tensor:
         device = torch.device("cuda", torch.cuda.current_device())
     flag = _index_err.get(device)
     if flag is None:
-        flag = torch.zeros(1, device=device, dtype=torch.int32)
+        flag = torch.zeros(2, device=device, dtype=torch.int32)     # [index out of range, non-finite input]
         _index_err[device] = flag
     return flag
 
@@ -373,7 +376,7 @@ def raise_if_index_error(device=None):
     """Synchronising check of the flag; raises like the reference's out-of-range gather would."""
     flags = list(_index_err.values()) if device is None else [index_error_flag(device)]
     for flag in flags:
-        if int(flag.item()) != 0:
+        if int(flag[0].item()) != 0:
             flag.zero_()
             raise IndexError("subject / layout index out of range for the weight table "
                              "(bm/models/common.py:57 would raise in `weights.gather`)")

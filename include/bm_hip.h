@@ -123,6 +123,9 @@ int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, 
  * the producers of one stream may share (per-workgroup partial maxima, folded by a one-workgroup kernel). */
 int bm_amax_ws_elems(void);
 int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
+/* Same pass, plus the reference's finiteness assert (bm/solver.py:258-260): *nonfinite_flag (device int, nullable)
+ * is set to 1 when x holds an inf or a nan. */
+int bm_amax_checked(const float* x, long n, float* out, float* amax_ws, int* nonfinite_flag, void* stream);
 int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked, const int* widx,
                     const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B, int Cin,
