@@ -214,7 +214,7 @@ def test_clip(h2_mode, H, B, Bc, Fd, T):
 
 
 def test_producers_publish_their_own_maximum(h2_mode, H):
-    """The elementwise kernels and the conv epilogue publish max|output| themselves (atomicMax on the bit pattern);
+    """The elementwise kernels and the conv epilogue publish max|output| themselves (per-workgroup partial maxima);
     the consuming contraction then needs no pass over the tensor."""
     g = _gen(11)
     B, C, T = 3, 64, 200
@@ -223,7 +223,7 @@ def test_producers_publish_their_own_maximum(h2_mode, H):
     scale, shift = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
 
     def published(t):
-        ver, ptr, slot = t._bm_amax
+        ver, ptr, slot = t._bm_amax[:3]
         assert ver == t._version and ptr == t.data_ptr()
         return float(slot.max())
 
