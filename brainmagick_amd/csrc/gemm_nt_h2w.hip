@@ -508,6 +508,10 @@ static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     return bm_check_launch("gemm_nt_h2w");
 }
 
+extern "C" int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
+                             long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M, int Cn,
+                             int T, int KS, int dil, int nsplit, void* stream);
+
 // part[split][m][c*KS + j] for one group of S consecutive segments (same contract as bm_gemm_nt without
 // order / seg); a_amax / x_amax: device pointers to max|a|, max|x| (bm_amax).  Only shapes
 // bm_gemm_nt_h2_covers() accepts.
@@ -518,8 +522,11 @@ extern "C" int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, con
     BM_REQUIRE(M > 0 && Cn > 0 && T > 0 && nsplit > 0 && S >= 0, "gemm_nt_h2: bad dims");
     const int fam = hg_family(S, 1, M, Cn, T, KS, dil, false);
     BM_REQUIRE(fam != 0, "gemm_nt_h2: shape not covered (M=%d Cn=%d T=%d KS=%d dil=%d)", M, Cn, T, KS, dil);
-    BM_REQUIRE(((long)(M - 1) * a_rstride + T) * 4 < 0x7f000000L && ((long)(Cn - 1) * x_rstride + T) * 4 < 0x7f000000L,
-               "gemm_nt_h2: a segment spans 2 GB or more");
+    // 32-bit byte offsets inside a segment: an operand whose segment spans 2 GB or more (2 048 wav2vec2-sized
+    // candidates on 8 GPUs) takes the 3 x bf16 entry point, which hands it to the 64-bit-addressed fp32 kernel
+    if (((long)(M - 1) * a_rstride + T) * 4 >= 0x7f000000L || ((long)(Cn - 1) * x_rstride + T) * 4 >= 0x7f000000L)
+        return bm_gemm_nt_x3(a, a_sstride, a_rstride, x, x_sstride, x_rstride, nullptr, nullptr, part, S, 1, M, Cn, T,
+                             KS, dil, nsplit, stream);
     GemmNTArgsH g;
     g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride; g.a_amax = a_amax;
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride; g.x_amax = x_amax;

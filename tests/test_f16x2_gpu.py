@@ -300,3 +300,17 @@ def test_parameters_are_packed_once_per_step(h2_mode, H):
         H._BATCH_PACK = True
     assert e3 == e2, (e2, e3)
     assert all(math.isfinite(v) for v in losses)
+
+
+def test_operand_spanning_2gb_takes_the_64bit_path(h2_mode, H):
+    """The wide kernels address a segment with 32-bit byte offsets; an operand whose rows span 2 GB or more
+    (2 048 wav2vec2-sized candidates on 8 GPUs) must be routed to the 64-bit-addressed kernel, not rejected."""
+    g = _gen(21)
+    M, Cn, T, stride = 256, 256, 512, 2_100_000                     # (Cn - 1) * stride * 4 bytes > 2 GB
+    a = torch.randn(M, T, generator=g)
+    rows = torch.randn(Cn, T, generator=g)
+    big = torch.zeros(Cn * stride, device="cuda")
+    big.view(Cn, stride)[:, :T] = rows.cuda()
+    part = H.gemm_nt_partials(a.cuda(), big, 1, M, Cn, T, (0, T), (0, stride))
+    ref = a.double() @ rows.double().t()
+    assert rel_l2(part.sum(0), ref) < FWD_TOL
