@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     constexpr int BUF = 2 * PLANE;                    // slots of one stage buffer (2 planes)
     constexpr int TN = MW * NS;                       // MFMAs of one term (one operand-plane pair, one k-step)
     constexpr int NXS = KS == 3 ? 3 : 1;              // tap shifts of the X fetches
+#ifdef HG_TRACE
+    const long long t_kernel0 = __builtin_readcyclecounter();
+    long long t_loop0 = t_kernel0, t_loop1 = t_kernel0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* lds = reinterpret_cast<u32x4*>(smem);      // [2 buffers][2 planes][A slots | X slots]
     const int tid = threadIdx.x;
@@ -332,6 +336,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
         bool was_edge = true;
 #ifdef HG_TRACE
         unsigned long long tr[8], tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        __builtin_amdgcn_sched_barrier(0);
+        t_loop0 = __builtin_readcyclecounter();
 #endif
         // stage k: MFMAs on buffer k & 1 -- six terms of MW NS MFMAs: k-step 0 lo*hi, hi*hi, hi*lo, k-step 1
         // likewise; the staging set holds chunk k + 1 (fetched during stage k - 1; a repeat of the last chunk in
@@ -406,6 +412,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #endif
         }
 #ifdef HG_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        t_loop1 = __builtin_readcyclecounter();
         if (blockIdx.x < 64 && lane == 0)
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) hg_trace_buf[(blockIdx.x * 4 + wave) * 8 + i_] = (long long)tacc[i_];
 #endif
@@ -454,6 +462,15 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
             }
         }
     }
+#ifdef HG_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partial tile has left the CU
+    if (blockIdx.x < 64 && lane == 0) {
+        long long* o = hg_trace_buf + (blockIdx.x * 4 + wave) * 8;
+        o[2] = t_loop0 - t_kernel0;                               // prologue
+        o[3] = t_loop1 - t_loop0;                                 // main loop
+        o[6] = (long long)__builtin_readcyclecounter() - t_loop1; // epilogue
+    }
+#endif
 }
 
 // tile family of a shape: 0 = not covered, 1 = 320 x 192 (<KS,5,3>), 2 = 256 x 128 (<1,4,2>)
