@@ -438,8 +438,12 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         else:
             nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G)
         if G > 1:
-            tiles = max(1, (M // 64) * (Cn // 64)) * G
-            nsplit = max(1, min(8, 512 // tiles)) if T >= 1024 else 1
+            # grouped (per-subject / per-layout) weight gradients run in the 160 x 128-tile kernels, two workgroups
+            # per CU: split each group's (segment, 32-sample chunk) list until ~512 workgroups exist, keeping at
+            # least 8 chunks per split
+            tiles = -(-M // 160) * -(-Cn // 128) * G
+            chunks = max(1, S // G) * -(-T // 32)
+            nsplit = max(1, min(8, 512 // tiles, chunks // 8))
     canonical = tuple(out_strides) == (M * Cn * KS, Cn * KS, KS, 1)
     if nsplit == 1 and canonical:
         part = out
