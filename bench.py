@@ -410,6 +410,10 @@ def main():
                    "step_tflops": seg_flops * B * world * args.steps / elapsed / 1e12},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                      "peak": peak_tf, "unit": "TFLOP/s", "frac": achieved / peak_tf,
+                     # information: the same ratio against what a register-only MFMA loop on random 16-bit operands
+                     # sustains on this chip (1 790 TF at a power-throttled ~1.75 GHz, scripts/micro/mfma_peak.hip)
+                     "frac_of_sustained_mfma": (achieved / (peak_tf * 1790.0 / 2500.0)
+                                                if args.dtype in ("f16x2", "f32x3", "bf16") else None),
                      "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
                      "traffic_source": traffic_src,
