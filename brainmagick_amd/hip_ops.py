@@ -198,6 +198,7 @@ def weights_changed():
 
 class _PackPlan:
     MAX_JOBS = 512           # e.g. many models in one test session: start over rather than grow without bound
+    KEEP = 3                 # parameter updates an entry survives without being asked for (a model that went away)
 
     def __init__(self, device):
         self.device = device
@@ -216,15 +217,25 @@ class _PackPlan:
             dst._bm_mode = "f16x2"
             dst._bm_groups = G
             # `src` is kept alive: the batched launch reads it through its raw pointer
-            e = self.entries[key] = dict(src=src, geom=geom, dst=dst, stamp=None)
+            e = self.entries[key] = dict(src=src, ptr=src.data_ptr(), geom=geom, dst=dst, stamp=None)
             self.table = None
+        e["used"] = _weights_epoch
         if e["stamp"] != (_weights_epoch, src._version):
             self.refresh()
         return e["dst"]
 
     def refresh(self):
         global pack_launches
+        # parameters nobody asked for lately (another model of the process, a re-seated `.data`) leave the plan
+        stale = [k for k, e in self.entries.items()
+                 if e["used"] < _weights_epoch - self.KEEP or e["src"].data_ptr() != e["ptr"]]
+        for k in stale:
+            del self.entries[k]
+        if stale:
+            self.table = None
         ents = list(self.entries.values())
+        if not ents:
+            return
         if self.table is None:
             nb = lib().bm_pack_h2_job_bytes()
             host = ctypes.create_string_buffer(nb * len(ents))
