@@ -302,3 +302,56 @@ def test_scale_reject_subset_follows_the_reference_getitem():
         _recordings: list = dataclasses.field(default_factory=list)
     plain = _subset(Plain(batch.meg, batch.features_mask), keep)
     assert plain._recordings == [] and plain.meg.shape[0] == 3
+
+
+def test_pack_plan_refresh_and_eviction_logic(monkeypatch):
+    """hip_ops._PackPlan (persistent packed parameters, one batched launch per parameter update) against a stub
+    library: one refresh per update however many parameters ask, torch-side edits are seen through the version
+    counter, parameters nobody asks for any more leave the plan."""
+    from brainmagick_amd import hip_ops as H
+
+    class StubLib:
+        def __init__(self):
+            self.batches = []
+
+        def bm_packed_weight_bytes_h2(self, G, M, Cin, KS):
+            return 64
+
+        def bm_pack_h2_job_bytes(self):
+            return 16
+
+        def bm_pack_h2_job_fill(self, job, src, dst, *rest):
+            return 10
+
+        def bm_pack_weights_h2_batch(self, table, njobs, total_blocks, stream):
+            self.batches.append((njobs, total_blocks))
+            return 0
+
+    stub = StubLib()
+    monkeypatch.setattr(H, "lib", lambda: stub)
+    monkeypatch.setattr(H, "_stream", lambda: None)
+    monkeypatch.setattr(H, "_weights_epoch", 0)
+    plan = H._PackPlan(torch.device("cpu"))
+    params = [torch.nn.Parameter(torch.randn(4, 3, 3)) for _ in range(3)]
+    geom = (1, 4, 3, 3, 0, 9, 3, 1, 0)
+    packed = [plan.get(p, geom) for p in params]
+    n_registration = len(stub.batches)                    # registration refreshes (one per new parameter)
+    assert stub.batches[-1] == (3, 30)
+    assert [plan.get(p, geom) is q for p, q in zip(params, packed)] == [True] * 3
+    assert len(stub.batches) == n_registration            # nothing changed: served from the plan
+    H.weights_changed()
+    for p in params:
+        plan.get(p, geom)
+    assert len(stub.batches) == n_registration + 1        # one launch for all three
+    with torch.no_grad():
+        params[1].mul_(2.0)                               # torch-side edit: version counter
+    plan.get(params[0], geom)
+    assert len(stub.batches) == n_registration + 1
+    plan.get(params[1], geom)
+    assert len(stub.batches) == n_registration + 2
+    # a parameter that is not asked for during KEEP + 1 updates leaves the plan
+    for _ in range(H._PackPlan.KEEP + 2):
+        H.weights_changed()
+        plan.get(params[0], geom)
+        plan.get(params[1], geom)
+    assert stub.batches[-1][0] == 2 and len(plan.entries) == 2
