@@ -533,6 +533,7 @@ extern "C" int bm_conv_h2_covers(int Cin, int M, int T, int KS, int dil) {
     if (!h2_enabled() || (KS != 1 && KS != 3)) return 0;
     if ((KS >> 1) * dil > 16 || T <= 128) return 0;
     if ((long)Cin * T * 4 >= 0x40000000L) return 0;
+    if ((long)Cin * KS > 3840) return 0;              // PACK_MAX_NK: a weight row must fit the packing kernel's LDS tile
     // padded rows are wasted MFMA work: leave tiny layers (tests, F = 16 heads) to the narrow kernels
     return (long)bm_conv_h2_mpad(M) * 2 <= (long)M * 3 || M >= 96;
 }
@@ -555,69 +556,98 @@ struct PackH2Job {
     int block0, nblocks;      // workgroups [block0, block0 + nblocks) of a batched launch belong to this job
 };
 
-__device__ __forceinline__ void pack_h2_row(const PackH2Job& jb, int block, float* red) {
+// PACK_ROWS consecutive rows per workgroup of 256 threads (one wavefront per row), staged through LDS so that both
+// source layouts are read along their contiguous direction: the forward layout a whole row at a time, the
+// transposed (data-gradient) layout PACK_ROWS x KS contiguous floats per channel -- read element by element it
+// touched a different cache line with every value and the 36 MB of parameters took 175 us to pack.
+#define PACK_ROWS 4
+#define PACK_MAX_NK 3840      // Cin * KS values of one row that the LDS tile holds (61 KB)
+
+__device__ __forceinline__ void pack_h2_rows(const PackH2Job& jb, int block, float* tile, float* rs) {
     const float* __restrict__ src = jb.src;
     const int M = jb.M, Cin = jb.Cin, KS = jb.KS, Mpad = jb.Mpad, nchunk = jb.nchunk, flip = jb.flip;
     const long sg = jb.sg, sm = jb.sm, sc = jb.sc, sj = jb.sj;
-    const int m = block % Mpad, g = block / Mpad;
+    const int rows_per_group = Mpad / PACK_ROWS;
+    const int g = block / rows_per_group, m0 = (block - g * rows_per_group) * PACK_ROWS;
     const float alpha = jb.alpha ? *jb.alpha : 1.f;
     const int nk = Cin * KS;
-    float mx = 0.f;
-    if (m < M)
-        for (int i = threadIdx.x; i < nk; i += blockDim.x) {
-            const int c = i / KS, j = i - c * KS;
-            mx = fmaxf(mx, fabsf(alpha * src[g * sg + m * sm + c * sc + j * sj]));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1. tile[r][c * KS + j] = alpha * w[m0 + r][c][j]; the faster of (row, channel) in memory runs inside
+    const float* base = src + g * sg + (long)m0 * sm;
+    const bool rows_inside = sm < sc;
+    for (int idx = tid; idx < PACK_ROWS * nk; idx += blockDim.x) {
+        int r, c, j;
+        if (rows_inside) {                  // idx = (c * PACK_ROWS + r) * KS + j
+            j = idx % KS;
+            const int t = idx / KS;
+            r = t % PACK_ROWS;
+            c = t / PACK_ROWS;
+        } else {                            // idx = (r * Cin + c) * KS + j
+            j = idx % KS;
+            const int t = idx / KS;
+            c = t % Cin;
+            r = t / Cin;
         }
-    mx = bm_wave_max(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        tile[r * nk + c * KS + j] = (m0 + r < M) ? alpha * base[r * sm + c * sc + j * sj] : 0.f;
+    }
     __syncthreads();
-    float s, inv;
-    h2_scale_from_amax(fmaxf(red[0], red[1]), s, inv);
-    if (threadIdx.x == 0) jb.wscale[(long)g * Mpad + m] = inv;
-    // slot index inside this row: (chunk, tap, group) -> 8 channels
+    // 2. row maxima -> scales (wavefront w owns row w)
+    {
+        float mx = 0.f;
+        for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, fabsf(tile[wave * nk + i]));
+        mx = bm_wave_max(mx);
+        float s, inv;
+        h2_scale_from_amax(mx, s, inv);
+        if (lane == 0) {
+            rs[wave] = s;
+            jb.wscale[(long)g * Mpad + m0 + wave] = inv;
+        }
+    }
+    __syncthreads();
+    // 3. the rows' 16-byte slots of both planes: slot q = (chunk, tap, 8-channel group); rows run fastest so that
+    //    neighbouring threads write neighbouring 16-byte slots
     const int nslots = nchunk * KS * 4;
     const long plane_stride = (long)4 * Mpad * 8;           // f16 elements of one plane of one (chunk, tap)
-    for (int q = threadIdx.x; q < nslots; q += blockDim.x) {
+    for (int t = tid; t < PACK_ROWS * nslots; t += blockDim.x) {
+        const int r = t % PACK_ROWS, q = t / PACK_ROWS;
         const int kg = q & 3;
         const int j = (q >> 2) % KS;
         const int chunk = (q >> 2) / KS;
+        const int jj = flip ? KS - 1 - j : j;
+        const float sr = rs[r];
         alignas(16) unsigned short hi[8];
         alignas(16) unsigned short lo[8];
 #pragma unroll
         for (int e8 = 0; e8 < 8; ++e8) {
             const int c = chunk * 32 + kg * 8 + e8;
-            float v = 0.f;
-            if (m < M && c < Cin) {
-                const int jj = flip ? KS - 1 - j : j;
-                v = alpha * src[g * sg + m * sm + c * sc + jj * sj] * s;
-            }
+            const float v = c < Cin ? tile[r * nk + c * KS + jj] * sr : 0.f;
             const _Float16 a = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)a);
             hi[e8] = __builtin_bit_cast(unsigned short, a);
             lo[e8] = __builtin_bit_cast(unsigned short, l);
         }
         const long stage = ((long)g * nchunk + chunk) * KS + j;
-        unsigned short* base = jb.dst + stage * 2 * plane_stride + ((long)kg * Mpad + m) * 8;
-        *reinterpret_cast<uint4*>(base) = *reinterpret_cast<const uint4*>(hi);
-        *reinterpret_cast<uint4*>(base + plane_stride) = *reinterpret_cast<const uint4*>(lo);
+        unsigned short* out = jb.dst + stage * 2 * plane_stride + ((long)kg * Mpad + m0 + r) * 8;
+        *reinterpret_cast<uint4*>(out) = *reinterpret_cast<const uint4*>(hi);
+        *reinterpret_cast<uint4*>(out + plane_stride) = *reinterpret_cast<const uint4*>(lo);
     }
 }
 
-__global__ __launch_bounds__(128) void pack_weights_h2_kernel(PackH2Job jb) {
-    __shared__ float red[2];
-    pack_h2_row(jb, blockIdx.x, red);
+__global__ __launch_bounds__(256) void pack_weights_h2_kernel(PackH2Job jb) {
+    extern __shared__ float pack_smem[];
+    pack_h2_rows(jb, blockIdx.x, pack_smem + PACK_ROWS, pack_smem);
 }
 
 // every weight tensor of a model in ONE launch: `jobs` (device memory) sorted by block0
-__global__ __launch_bounds__(128) void pack_weights_h2_batch_kernel(const PackH2Job* __restrict__ jobs, int njobs) {
-    __shared__ float red[2];
+__global__ __launch_bounds__(256) void pack_weights_h2_batch_kernel(const PackH2Job* __restrict__ jobs, int njobs) {
+    extern __shared__ float pack_smem[];
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {                                   // last job with block0 <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackH2Job jb = jobs[lo];
-    pack_h2_row(jb, blockIdx.x - jb.block0, red);
+    pack_h2_rows(jb, blockIdx.x - jb.block0, pack_smem + PACK_ROWS, pack_smem);
 }
 
 static int pack_h2_fill(PackH2Job& jb, const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
@@ -632,7 +662,8 @@ static int pack_h2_fill(PackH2Job& jb, const float* src, void* dst, int G, int M
     jb.alpha = alpha_ptr;
     jb.sg = sg; jb.sm = sm; jb.sc = sc; jb.sj = sj;
     jb.M = M; jb.Cin = Cin; jb.KS = KS; jb.flip = flip;
-    jb.block0 = 0; jb.nblocks = G * jb.Mpad;
+    BM_REQUIRE(Cin * KS <= PACK_MAX_NK, "pack_weights_h2: Cin * KS = %d exceeds %d", Cin * KS, PACK_MAX_NK);
+    jb.block0 = 0; jb.nblocks = G * jb.Mpad / PACK_ROWS;
     return BM_OK;
 }
 
@@ -640,7 +671,8 @@ extern "C" int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int
                                   long sc, long sj, int flip, const float* alpha_ptr, void* stream) {
     PackH2Job jb;
     if (int rc = pack_h2_fill(jb, src, dst, G, M, Cin, KS, sg, sm, sc, sj, flip, alpha_ptr)) return rc;
-    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3((unsigned)jb.nblocks), dim3(128), 0, (hipStream_t)stream, jb);
+    hipLaunchKernelGGL(pack_weights_h2_kernel, dim3((unsigned)jb.nblocks), dim3(256),
+                       (size_t)(PACK_ROWS + PACK_ROWS * Cin * KS) * sizeof(float), (hipStream_t)stream, jb);
     return bm_check_launch("pack_weights_h2");
 }
 
@@ -659,9 +691,11 @@ extern "C" int bm_pack_h2_job_fill(void* job, const float* src, void* dst, int G
     return jb.nblocks;
 }
 
-extern "C" int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
+extern "C" int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, int max_nk, void* stream) {
     BM_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_weights_h2_batch: bad arguments");
-    hipLaunchKernelGGL(pack_weights_h2_batch_kernel, dim3((unsigned)total_blocks), dim3(128), 0, (hipStream_t)stream,
+    BM_REQUIRE(max_nk > 0 && max_nk <= PACK_MAX_NK, "pack_weights_h2_batch: max_nk = %d (largest Cin * KS of the jobs)", max_nk);
+    hipLaunchKernelGGL(pack_weights_h2_batch_kernel, dim3((unsigned)total_blocks), dim3(256),
+                       (size_t)(PACK_ROWS + PACK_ROWS * max_nk) * sizeof(float), (hipStream_t)stream,
                        (const PackH2Job*)jobs_dev, njobs);
     return bm_check_launch("pack_weights_h2_batch");
 }

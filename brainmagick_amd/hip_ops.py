@@ -248,7 +248,8 @@ class _PackPlan:
                 block0 += n
             self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
             self.total_blocks = block0
-        check(lib().bm_pack_weights_h2_batch(_p(self.table), len(ents), self.total_blocks, _stream()),
+        max_nk = max(e["geom"][2] * e["geom"][3] for e in ents)          # Cin * KS
+        check(lib().bm_pack_weights_h2_batch(_p(self.table), len(ents), self.total_blocks, max_nk, _stream()),
               "bm_pack_weights_h2_batch")
         pack_launches += 1
         for e in ents:

@@ -114,11 +114,11 @@ int bm_pack_weights_h2(const float* src, void* dst, int G, int M, int Cin, int K
 /* Batched packing: every weight tensor of a model re-packed by ONE launch per optimizer step.  The host fills a
  * table of bm_pack_h2_job_bytes()-byte jobs with bm_pack_h2_job_fill (same arguments as bm_pack_weights_h2 plus the
  * job's first workgroup `block0`; returns the job's workgroup count, < 0 on bad arguments), copies the table to
- * device memory, and calls bm_pack_weights_h2_batch(table, njobs, sum of the workgroup counts). */
+ * device memory, and calls bm_pack_weights_h2_batch(table, njobs, sum of the workgroup counts, largest Cin * KS of the jobs). */
 int bm_pack_h2_job_bytes(void);
 int bm_pack_h2_job_fill(void* job, const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
                         long sc, long sj, int flip, const float* alpha_ptr, int block0);
-int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, void* stream);
+int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, int max_nk, void* stream);
 /* amax slots and workspace: a slot is 8 floats whose maximum is max|x|; `amax_ws` is 16384 floats of scratch that
  * the producers of one stream may share (per-workgroup partial maxima, folded by a one-workgroup kernel). */
 int bm_amax_ws_elems(void);

@@ -323,7 +323,8 @@ def test_pack_plan_refresh_and_eviction_logic(monkeypatch):
         def bm_pack_h2_job_fill(self, job, src, dst, *rest):
             return 10
 
-        def bm_pack_weights_h2_batch(self, table, njobs, total_blocks, stream):
+        def bm_pack_weights_h2_batch(self, table, njobs, total_blocks, max_nk, stream):
+            assert max_nk == 9
             self.batches.append((njobs, total_blocks))
             return 0
 
