@@ -77,13 +77,19 @@ __global__ void group_by_index_kernel(const long* __restrict__ idx, int B, int G
         seg[G] = run;
     }
     __syncthreads();
-    // each group is filled in ascending segment order by ONE thread -> deterministic (the scan reads LDS: from
-    // global memory its B dependent loads per thread took 28 us at B = 256)
+    // each group is filled in ascending segment order by ONE thread -> deterministic (the scan reads LDS, eight
+    // values per round: one dependent global load per element took 28 us at B = 256)
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         int pos = counts[g];
         const int end = counts[g + 1];
-        for (int b = 0; b < B && pos < end; ++b)
-            if (ids[b] == g) order[pos++] = b;
+        for (int b0 = 0; b0 < B && pos < end; b0 += 8) {      // 8 independent LDS reads per round
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? ids[b0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] == g) order[pos++] = b0 + u;
+        }
     }
 }
 
