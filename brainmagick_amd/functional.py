@@ -5,7 +5,6 @@ bm/solver.py:385, so the HIP backward kernels must hang off the autograd tape).
 No function here touches the CPU oracle or a torch compute op for the hot path; torch is the
 tape, the allocator and the stream.
 """
-import typing as tp
 
 import torch
 
