@@ -179,88 +179,130 @@ def retrieval_block(workload, B, steps, dev, n_train=16, n_held=4, noise=3.4):
             "data": "planted-latent synthetic world (brainmagick_amd/synthetic.py), default compute mode"}
 
 
-def retrieval_parity_block(dev, steps=120, noise=0.8):
-    """HIP path and CPU oracle trained side by side (same initial state, same planted batches, reduced
-    model so that the oracle finishes in seconds): top-10 / top-1 retrieval on 1 024 held-out segments."""
+# Dimensions of the long-horizon parity run: like tests/test_model_gpu.py::PARITY_DIMS, chosen so that every
+# contraction runs in the kernels of the headline benchmark (wide f16x2 conv / weight gradient / score kernels).
+PARITY_DIMS = dict(C=64, T=192, F=128, S=4, B=128, hidden=256, merger_channels=256, depth=4)
+PARITY_NOISE = 1.0
+
+
+def retrieval_parity_block(dev, steps=120, noise=PARITY_NOISE):
+    """HIP path and CPU oracle trained side by side THROUGH THE HEADLINE KERNELS (same initial state, a fresh planted
+    batch every step, model sized so that the wide f16x2 kernels cover its layers and the oracle still takes
+    ~0.5 s / step): top-10 / top-1 retrieval on 1 024 held-out segments, largest relative loss gap."""
     import copy
     from oracle import bm_oracle as O
     from brainmagick_amd import retrieval
     from brainmagick_amd.losses import ClipLoss
+    d = PARITY_DIMS
     cfg = dict(O.CLIP_CONV_CFG)
-    cfg.update(merger_pos_dim=128, merger_channels=32, initial_linear=32, depth=6, merger_dropout=0.0)
-    C, T, Fd, S, B, hidden, n_batches, n_held = 24, 96, 16, 4, 32, 48, 32, 1024
+    cfg.update(merger_pos_dim=128, merger_channels=d["merger_channels"], initial_linear=d["merger_channels"],
+               depth=d["depth"], merger_dropout=0.0)
+    C, T, Fd, S, B, hidden, n_held = d["C"], d["T"], d["F"], d["S"], d["B"], d["hidden"], 1024
     torch.manual_seed(5)
     model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
     oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, hidden, Fd)
     solver = Solver(model, device=str(dev))
-    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True, noise=noise)
-               for i in range(n_batches)]
-    worst = 0.0
-    for step in range(steps):
-        sb = batches[step % n_batches]
-        lh = float(solver.train_step(sb))
-        lr_ = float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index, sb.features)[0])
-        worst = max(worst, abs(lh - lr_) / abs(lr_))
-    held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
-    est_hip, cand = solver.predict(held)
-    acc_hip = retrieval.segment_topk_accuracy(ClipLoss().to(dev), est_hip, cand, topks=(1, 10))
-    probs_ref = O.clip_probabilities(oracle.forward(held.meg, held.positions(), held.subject_index), held.features)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, prev_threads))
+    worst, kernels = 0.0, set()
+    try:
+        for step in range(steps):
+            sb = synthetic.make_batch(B, C, T, Fd, S, seed=100 + step, planted=True, noise=noise)
+            timer = None
+            if step == steps - 1:
+                timer = hip_ops.KernelTimer()
+                hip_ops.set_kernel_timer(timer)
+            lh = float(solver.train_step(sb))
+            if timer is not None:
+                hip_ops.set_kernel_timer(None)
+                kernels = {r[0] for r in timer.records}
+            lr_ = float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index, sb.features)[0])
+            worst = max(worst, abs(lh - lr_) / abs(lr_))
+        held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
+        est_hip, cand = solver.predict(held)
+        acc_hip = retrieval.segment_topk_accuracy(ClipLoss().to(dev), est_hip, cand, topks=(1, 10))
+        probs_ref = O.clip_probabilities(oracle.forward(held.meg, held.positions(), held.subject_index),
+                                         held.features)
+    finally:
+        torch.set_num_threads(prev_threads)
+        hip_ops.set_kernel_timer(None)
     labels = torch.arange(n_held)
     return {"hip_top10": acc_hip["top10"], "oracle_top10": O.topk_accuracy(probs_ref, labels, labels, 10),
             "hip_top1": acc_hip["top1"], "oracle_top1": O.topk_accuracy(probs_ref, labels, labels, 1),
             "max_rel_loss_gap": worst, "train_steps": steps, "held_out_segments": n_held,
-            "planted_noise": noise, "model": "clip_conv reduced (hidden 48, depth 6, C=24, T=96, F=16), batch 32"}
+            "planted_noise": noise, "kernels_of_the_last_step": sorted(kernels),
+            "model": f"clip_conv reduced to the smallest size the wide f16x2 kernels cover (hidden {hidden}, depth "
+                     f"{d['depth']}, C={C}, T={T}, F={Fd}), batch {B}, a fresh batch every step"}
 
 
 def clip_roofline(dev, mode, reps=20):
-    """The contrastive contraction scores = est . cand^T over K = F*T (bm/losses.py:91-95) at batch 256 for the
-    cfg2 (F=120) and cfg3 (F=1024) shapes: HIP-event time of the whole forward (candidate norms are NOT
-    included: constant candidates; scores GEMM + split fold + row softmax / CE) and of the scores kernel alone."""
+    """The contrastive contraction scores = est . cand^T over K = F*T (bm/losses.py:91-95) at batch 256: the cfg2
+    (F=120) and cfg3 (F=1024) shapes against the rank's own 256 candidates, and the cfg4 shapes against the 2 048
+    whole-node candidates of 8 ranks (F=1024: a 3 GB operand, walked in row blocks).  HIP-event time of the whole
+    forward (candidate norms NOT included: constant candidates; scores GEMM + split fold + row softmax / CE) and of
+    the score kernel(s) alone."""
     from brainmagick_amd import functional as BF
     out = {}
-    for name, F in (("cfg2", 120), ("cfg3", 1024)):
+    for name, F, Bc in (("cfg2", 120, 256), ("cfg3", 1024, 256), ("cfg4_mel_2048", 120, 2048),
+                        ("cfg4_w2v_2048", 1024, 2048)):
         B, T = 256, 360
         K = F * T
         g = torch.Generator(device="cpu").manual_seed(3)
         est = torch.randn(B, F, T, generator=g).to(dev)
-        cand = torch.randn(B, F, T, generator=g).to(dev)
+        cand = torch.empty(Bc, F, T, device=dev)
+        for r0 in range(0, Bc, 256):
+            cand[r0:r0 + 256] = torch.randn(256, F, T, generator=g).to(dev)
         inv = hip_ops.clip_inv_norms(cand)
-        for _ in range(3):
+        n_rep = reps if Bc == 256 else max(3, reps // 4)
+        for _ in range(2):
             BF.clip_forward_timed(est, cand, inv, None)
-        timer = hip_ops.KernelTimer()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        for _ in range(reps):
+        for _ in range(n_rep):
             BF.clip_forward_timed(est, cand, inv, None)
         ev1.record()
         torch.cuda.synchronize()
-        fwd_us = ev0.elapsed_time(ev1) / reps * 1e3
-        for _ in range(reps):
+        fwd_us = ev0.elapsed_time(ev1) / n_rep * 1e3
+        timer = hip_ops.KernelTimer()
+        for _ in range(n_rep):
             BF.clip_forward_timed(est, cand, inv, timer)
         torch.cuda.synchronize()
         ks = timer.summary()
-        kname = max(ks, key=lambda k: ks[k]["avg_ms"])
-        t = ks[kname]["avg_ms"] * 1e-3
-        flops = 2.0 * B * B * K
-        nbytes = 4.0 * (B + B) * K
+        t = sum(v["avg_ms"] * v["launches"] for v in ks.values()) / n_rep * 1e-3      # score kernels per forward
+        kname = max(ks, key=lambda k: ks[k]["avg_ms"] * ks[k]["launches"])
+        flops = 2.0 * B * Bc * K
+        nbytes = 4.0 * (B + Bc) * K
         peak = MODE_PEAK_TFLOPS[mode]
         mfma_frac = flops / t / 1e12 / peak
         hbm_frac = nbytes / t / 1e9 / PEAK_HBM_GBS
-        out[name] = {"kernel": kname, "K": K, "kernel_us": t * 1e6, "forward_us": fwd_us,
+        out[name] = {"kernel": kname, "launches_per_forward": sum(v["launches"] for v in ks.values()) / n_rep,
+                     "B": B, "candidates": Bc, "K": K, "kernel_us": t * 1e6, "forward_us": fwd_us,
                      "achieved_tflops": flops / t / 1e12, "peak_tflops": peak, "mfma_frac": mfma_frac,
                      "achieved_gbs": nbytes / t / 1e9, "peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_frac,
                      "bound": "mfma" if mfma_frac >= hbm_frac else "hbm", "frac": max(mfma_frac, hbm_frac)}
+        del est, cand, inv
+        torch.cuda.empty_cache()
     return out
+
+
+def self_launch_command(gpus: int, argv, port=None):
+    """(command, environment) of the re-launch under torch.distributed.run: one rank per GPU of this node,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve) on a free port."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    return cmd, env
 
 
 def self_launch(args) -> int:
     """python bench.py --gpus N without a torchrun environment: re-launch under torch.distributed.run."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd, env = self_launch_command(args.gpus, sys.argv[1:])
     return subprocess.call(cmd, env=env)
 
 
@@ -294,12 +336,21 @@ class BatchStream:
             self.draws.append(recs)
         self.n = n
         self.step = 0
+        self._peeked = None
+
+    def _at(self, step):
+        sb = self.batches[step % self.n]
+        return sb.replace(_recordings=self.draws[step % len(self.draws)])
 
     def next(self):
-        sb = self.batches[self.step % self.n]
-        recs = self.draws[self.step % len(self.draws)]
+        """(this step's batch, the next step's batch): the second one lets the Solver start the whole-node
+        candidate all-gather of step k + 1 behind step k's backward (Solver.prefetch)."""
+        if self._peeked is None:
+            self._peeked = self._at(self.step)
+        cur = self._peeked
         self.step += 1
-        return sb.replace(_recordings=recs)
+        self._peeked = self._at(self.step)
+        return cur, self._peeked
 
 
 def main():
@@ -350,13 +401,16 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
-            loss = solver.train_step(stream.next())
+            cur, nxt = stream.next()
+            loss = solver.train_step(cur, next_batch=nxt if prefetch else None)
         distrib.barrier()
         torch.cuda.synchronize()
         return distrib.max_over_ranks(time.perf_counter() - t0), loss
 
+    prefetch = negatives == "node" and world > 1
     for _ in range(args.warmup):
-        solver.train_step(stream.next())
+        cur, nxt = stream.next()
+        solver.train_step(cur, next_batch=nxt if prefetch else None)
     elapsed, loss = timed_steps(args.steps)
     final_loss = float(loss)
 
@@ -374,7 +428,7 @@ def main():
                 continue
             hip_ops.set_compute_dtype(mode)
             k2 = max(2, args.steps // 4)
-            solver.train_step(stream.next())
+            solver.train_step(stream.next()[0])
             e2, _ = timed_steps(k2)
             other_modes[mode] = {"compute_mode": mode, "steps": k2, "ms_per_step": e2 / k2 * 1e3,
                                  "value": world * B * k2 / e2, "unit": "segments/s"}
@@ -406,6 +460,8 @@ def main():
                                f"({n_params} params) + ClipLoss + Adam",
                    "batch_per_gpu": B, "global_batch": world * B, "negatives": negatives,
                    "parallelism": f"dp{world}", "comm": distrib.comm_kind(), "rccl_world": world,
+                   "candidate_gather": ("prefetched one step ahead on a side stream" if prefetch else
+                                        ("in front of the forward" if negatives == "node" else "none")),
                    "distinct_batches": stream.n, "final_loss": final_loss,
                    "step_tflops": seg_flops * B * world * args.steps / elapsed / 1e12},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,

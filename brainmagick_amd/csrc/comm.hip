@@ -77,6 +77,10 @@ int nccl_fail(const char* what, ncclResult_t r) {
 
 extern "C" int bm_comm_unique_id_bytes(void) { return NCCL_UNIQUE_ID_BYTES; }
 
+// 0 when librccl can be opened and exports every symbol bound above (a LOCAL check: the host agrees on it over
+// all ranks before anybody enters the collective ncclCommInitRank)
+extern "C" int bm_comm_available(void) { return load_rccl(); }
+
 extern "C" int bm_comm_unique_id(void* out_id) {
     BM_REQUIRE(out_id, "bm_comm_unique_id: null pointer");
     if (int rc = load_rccl()) return rc;

@@ -708,8 +708,12 @@ __global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x,
     __shared__ float sh[16];
     float mx = 0.f;
     unsigned top = 0u;                                  // largest |x| bit pattern: >= 0x7f800000 <=> inf / nan seen
-    const long n4 = n >> 2;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
+    // a tensor that is only 4-byte aligned (a batch slice such as meg[1:] with C * T odd): `head` scalar elements
+    // up to the first 16-byte boundary, the vector body from there, the scalar tail behind it
+    long head = (long)((16u - (unsigned)((uintptr_t)x & 15u)) & 15u) >> 2;
+    if (head > n) head = n;
+    const long n4 = (n - head) >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + head);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = x4[i];
         mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -717,11 +721,14 @@ __global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x,
                   max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu,
                                                                __float_as_uint(v.w) & 0x7fffffffu)));
     }
-    if (blockIdx.x == 0)
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
-            mx = fmaxf(mx, fabsf(x[i]));
-            top = max(top, __float_as_uint(x[i]) & 0x7fffffffu);
+    if (blockIdx.x == 0) {
+        const long tail0 = head + (n4 << 2);
+        for (long i = threadIdx.x; i < head + (n - tail0); i += blockDim.x) {
+            const long k = i < head ? i : tail0 + (i - head);
+            mx = fmaxf(mx, fabsf(x[k]));
+            top = max(top, __float_as_uint(x[k]) & 0x7fffffffu);
         }
+    }
     if (nonfinite && top >= 0x7f800000u) atomicOr(nonfinite, 1);     // rare: at most one atomic per thread
     bm_publish_amax(mx, ws, sh);
 }
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(1024) void amax_kernel(const float* __restrict__ x,
 // `torch.isfinite(x).all()` asserts (bm/solver.py:258-260) ride on the pass that the f16x2 scale needs anyway.
 extern "C" int bm_amax_checked(const float* x, long n, float* out, float* ws, int* nonfinite_flag, void* stream) {
     BM_REQUIRE(x && out && ws && n >= 0, "amax: bad arguments");
-    BM_REQUIRE(((uintptr_t)x & 15) == 0, "amax: x must be 16-byte aligned");
+    BM_REQUIRE(((uintptr_t)x & 3) == 0, "amax: x must be 4-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     long blocks = (n / 4 + 1023) / 1024;
     blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);

@@ -44,13 +44,19 @@ def _forced() -> bool:
 class _TorchComm:
     """torch.distributed process group: "gloo" (CPU tests) or "nccl" (= RCCL through PyTorch, fallback)."""
 
-    def __init__(self, backend: str):
+    def __init__(self, backend: str, store=None):
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         if backend == "gloo" and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the container hostname may not resolve
         if not dist.is_initialized():
-            dist.init_process_group(backend=backend)
+            if store is not None:
+                # the rendezvous store this process already holds (outside torchrun rank 0 HOSTS it on
+                # MASTER_PORT: a second env:// rendezvous would die with EADDRINUSE)
+                dist.init_process_group(backend=backend, store=dist.PrefixStore("bm_pg", store),
+                                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+            else:
+                dist.init_process_group(backend=backend)
         self.backend = backend
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
@@ -96,14 +102,32 @@ class _TorchComm:
             dist.destroy_process_group()
 
 
+_store_cache: tp.Optional[tp.Any] = None
+
+
 def _rendezvous_store(rank: int, world: int):
     """The TCP store of the torchrun / env:// rendezvous (the agent's store under torchrun, else rank 0
-    hosts it on MASTER_ADDR:MASTER_PORT).  Host-side key/value plumbing only."""
-    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("MASTER_PORT", "29500"))
-    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
-    return dist.TCPStore(host, port, world, is_master=(rank == 0 and not agent),
-                         timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    hosts it on MASTER_ADDR:MASTER_PORT).  Host-side key/value plumbing only; one per process."""
+    global _store_cache
+    if _store_cache is None:
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500"))
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+        _store_cache = dist.TCPStore(host, port, world, is_master=(rank == 0 and not agent),
+                                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    return _store_cache
+
+
+def _all_ranks_ok(store, key: str, rank: int, world: int, ok: bool) -> bool:
+    """Every rank publishes whether a LOCAL step worked and reads everybody's answer: the communicator choice
+    (RCCL behind the C-ABI or the torch.distributed fallback) must be the same on every rank, or the job
+    deadlocks with mixed communicators."""
+    store.set(f"{key}/{rank}", b"1" if ok else b"0")
+    return all(bytes(store.get(f"{key}/{r}")) == b"1" for r in range(world))
+
+
+class RcclUnavailable(RuntimeError):
+    """RCCL through the C-ABI cannot be used on at least one rank (agreed through the rendezvous store)."""
 
 
 class _RcclComm:
@@ -121,23 +145,39 @@ class _RcclComm:
         if "BM_RCCL_LIB" not in os.environ and os.path.exists(rccl):
             os.environ["BM_RCCL_LIB"] = rccl           # the copy PyTorch ships and tests on this driver
         nbytes = self._lib.bm_comm_unique_id_bytes()
-        key = f"bm_comm/{_RcclComm._generation}/id"
+        gen = _RcclComm._generation
         _RcclComm._generation += 1
-        if self.world == 1:
-            uid = ctypes.create_string_buffer(nbytes)
-            check(self._lib.bm_comm_unique_id(uid), "bm_comm_unique_id")
-            uid = uid.raw
-            self._store = None
+        key = f"bm_comm/{gen}"
+        self._h = None
+        self._store = _rendezvous_store(self.rank, self.world) if self.world > 1 else None
+        # phase 1 (local, cannot hang): librccl loads and exports what comm.hip binds -- agreed over all ranks
+        # BEFORE anybody enters the collective ncclCommInitRank
+        loaded = self._lib.bm_comm_available() == 0
+        if self._store is not None:
+            loaded = _all_ranks_ok(self._store, key + "/loaded", self.rank, self.world, loaded)
+        if not loaded:
+            raise RcclUnavailable("librccl could not be loaded on at least one rank: " +
+                                  (self._lib.bm_last_error() or b"").decode())
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(nbytes)
+            check(self._lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
+            uid = buf.raw
+            if self._store is not None:
+                self._store.set(key + "/id", uid)
         else:
-            self._store = _rendezvous_store(self.rank, self.world)
-            if self.rank == 0:
-                buf = ctypes.create_string_buffer(nbytes)
-                check(self._lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
-                self._store.set(key, buf.raw)
-            uid = bytes(self._store.get(key))
+            uid = bytes(self._store.get(key + "/id"))
+        # phase 2: the communicator itself; the outcome is agreed again so that a rank whose init failed does
+        # not leave the others with a communicator nobody else joins
         handle = ctypes.c_void_p()
-        check(self._lib.bm_comm_init(uid, self.world, self.rank, self.device, ctypes.byref(handle)),
-              "bm_comm_init")
+        rc = self._lib.bm_comm_init(uid, self.world, self.rank, self.device, ctypes.byref(handle))
+        ok = rc == 0
+        msg = "" if ok else (self._lib.bm_last_error() or b"").decode()
+        if self._store is not None:
+            ok = _all_ranks_ok(self._store, key + "/init", self.rank, self.world, ok)
+        if not ok:
+            if rc == 0:
+                self._lib.bm_comm_destroy(handle)
+            raise RcclUnavailable(f"ncclCommInitRank failed on at least one rank {msg}")
         self._h = handle
         self.kind = "rccl/c-abi"
 
@@ -213,16 +253,30 @@ def comm_kind() -> str:
     return _comm.kind if _comm is not None else "none"
 
 
+def _adopt_torch_group():
+    """A process group somebody else initialised (``flashy.distrib.init()`` at bm/train.py:139 does exactly
+    ``torch.distributed.init_process_group``): without this, a maintainer who keeps that call and only swaps in
+    ``sharded_step`` would train N replicas with NO gradient exchange, silently.  The group is adopted as the
+    communicator the first time anything here asks."""
+    global _comm
+    if _comm is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        _comm = _TorchComm(str(dist.get_backend()))
+    return _comm
+
+
 def is_distributed() -> bool:
-    return _comm is not None and (_comm.world > 1 or _forced())
+    c = _adopt_torch_group()
+    return c is not None and (c.world > 1 or _forced())
 
 
 def rank() -> int:
-    return _comm.rank if _comm is not None else 0
+    c = _adopt_torch_group()
+    return c.rank if c is not None else 0
 
 
 def world_size() -> int:
-    return _comm.world if _comm is not None else 1
+    c = _adopt_torch_group()
+    return c.world if c is not None else 1
 
 
 def init(backend: tp.Optional[str] = None):
@@ -241,13 +295,15 @@ def init(backend: tp.Optional[str] = None):
         backend = "rccl" if torch.cuda.is_available() else "gloo"
         if backend == "rccl" and os.environ.get("BM_COMM", "") == "torch":
             backend = "nccl"
-    if backend == "rccl":
+    if dist.is_initialized() and backend in ("gloo", "nccl"):
+        _comm = _TorchComm(backend)           # adopt the group that already exists
+    elif backend == "rccl":
         try:
             _comm = _RcclComm()
-        except Exception as exc:      # librccl not loadable / no communicator: same on every rank of a node
+        except RcclUnavailable as exc:        # agreed by every rank through the store: all fall back together
             import warnings
             warnings.warn(f"RCCL through the C-ABI is unavailable ({exc}); using torch.distributed's binding")
-            _comm = _TorchComm("nccl")
+            _comm = _TorchComm("nccl", store=_store_cache)
     else:
         _comm = _TorchComm(backend)
 
@@ -292,16 +348,29 @@ def hip_ops_weights_changed():
     hip_ops.weights_changed()
 
 
-def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None) -> None:
+_SHARD_DEFAULT = os.environ.get("BM_SHARD_OPTIMIZER", "1") == "1"
+
+
+def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None, shard: tp.Optional[bool] = None) -> None:
     """``flashy.distrib.sync_model`` + ``optimizer.step()`` (bm/solver.py:386-387) on the flat bucket:
     reduce-scatter(grads) -> Adam on the own shard (mean over ranks via grad_scale) -> all-gather
-    (params); float buffers (BatchNorm running statistics) averaged with one all-reduce."""
+    (params); float buffers (BatchNorm running statistics) averaged with one all-reduce.
+
+    ``shard=False`` (default from ``BM_SHARD_OPTIMIZER=0``): one in-place all-reduce of the gradients and the
+    full Adam on every rank -- same bytes on the wire, N times the (tiny) optimizer work, and the Adam moments
+    stay complete on every rank, so a rank-0-only ``optimizer.state_dict()`` needs no ``gather_moments()``."""
     if not is_distributed():
         optimizer.step()
         return
-    shard = sync_flat_gradients(optimizer)
-    optimizer.step(shard=shard, grad_scale=1.0 / world_size())
-    _comm.all_gather_shards(optimizer.flat_param)
+    if shard is None:
+        shard = _SHARD_DEFAULT
+    if shard:
+        bounds = sync_flat_gradients(optimizer)
+        optimizer.step(shard=bounds, grad_scale=1.0 / world_size())
+        _comm.all_gather_shards(optimizer.flat_param)
+    else:
+        _comm.all_reduce(optimizer.flat_grad)
+        optimizer.step(grad_scale=1.0 / world_size())
     hip_ops_weights_changed()               # parameters were written through raw pointers: packed copies are stale
     if buffers is not None:
         buffers.average()
@@ -416,9 +485,16 @@ class CandidateGather:
             _comm.all_gather(out, candidates)
         self._out = out
 
+    def cancel(self):
+        """Drop a gather that was started for a batch nobody will train on (the collective itself still runs to
+        completion on the side stream: every rank issued it)."""
+        self._out = None
+
     def wait(self) -> tp.Tuple[torch.Tensor, int]:
         out = self._out
         self._out = None
+        if out is None:
+            raise RuntimeError("CandidateGather.wait() without a matching start()")
         if not is_distributed():
             return out, 0
         if self.stream is not None and out.is_cuda:

@@ -247,6 +247,37 @@ class ChannelMergerFn(torch.autograd.Function):
         return dmeg, dheads, None, None, None, None
 
 
+# The wide kernels address one operand with 32-bit byte offsets and the conv stages a [Cin, T] window per segment:
+# a candidate set beyond 1 GB (2 048 wav2vec2-sized candidates gathered from 8 GPUs = 3 GB) is walked in row
+# blocks -- which are also the blocks the per-rank gather delivers.
+_CLIP_BLOCK_BYTES = 0x3f000000
+
+
+def _candidate_blocks(Bc: int, K: int):
+    """[(first row, rows)] such that every block's [rows, K] fp32 slab stays below _CLIP_BLOCK_BYTES."""
+    if Bc * K * 4 < _CLIP_BLOCK_BYTES:
+        return [(0, Bc)]
+    rows = max(1, _CLIP_BLOCK_BYTES // (K * 4))
+    if rows >= 128:
+        rows -= rows % 128
+    return [(r0, min(rows, Bc - r0)) for r0 in range(0, Bc, rows)]
+
+
+def _clip_raw_scores(estimate, candidate, B, Bc, K):
+    """Split-K partial tiles [nsplit, B, Bc] of est . cand^T (one launch), or -- for a candidate set walked in
+    blocks -- the folded products as a [1, B, Bc] "partial" (one launch + fold per block)."""
+    blocks = _candidate_blocks(Bc, K)
+    if len(blocks) == 1:
+        return H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+    raw = torch.empty(1, B, Bc, device=estimate.device, dtype=torch.float32)
+    cand2 = candidate.view(Bc, K)
+    for r0, rows in blocks:
+        blk = H.share_amax(candidate, cand2[r0:r0 + rows])
+        H.gemm_nt(estimate, blk, 1, B, rows, K, 1, 1, a_strides=(0, K), x_strides=(0, K),
+                  out=raw.view(-1)[r0:], out_strides=(0, Bc, 1, 0), force_f32=True)
+    return raw
+
+
 class ClipLossFn(torch.autograd.Function):
     """ClipLoss.forward (bm/losses.py:104-114): scores = est . cand^T * inv_norm (split-K MFMA GEMM
     over K = F*T), row-wise cross entropy with the target on the diagonal; the backward is a second
@@ -259,7 +290,7 @@ class ClipLossFn(torch.autograd.Function):
         K = estimate.numel() // B
         assert candidate.numel() // Bc == K
         inv = H.clip_inv_norms(candidate)
-        part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+        part = _clip_raw_scores(estimate, candidate, B, Bc, K)
         scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True,
                                              target_offset=target_offset)
         if ctx.needs_input_grad[1]:
@@ -277,19 +308,28 @@ class ClipLossFn(torch.autograd.Function):
         B, Bc = dscaled.shape
         K = candidate.numel() // Bc
         alpha = _c(dloss).view(1)
+        blocks = _candidate_blocks(Bc, K)
+        cand2 = candidate.view(Bc, K)
         dest = None
         if ctx.needs_input_grad[0]:
-            wp = H.pack_weights(dscaled, 1, B, Bc, 1, 0, Bc, 1, 0, alpha=alpha, shape=(K, 1))
-            _, dest, _ = H.conv_nn(candidate.view(1, Bc, K), wp, B, 1, 1)
+            # dEst = sum over candidate blocks of dScores[:, block] . cand[block]; the running sum is the
+            # conv epilogue's residual operand, written in place
+            for r0, rows in blocks:
+                wp = H.pack_weights(dscaled.view(-1)[r0:], 1, B, rows, 1, 0, Bc, 1, 0, alpha=alpha, shape=(K, 1))
+                blk = cand2[r0:r0 + rows] if len(blocks) == 1 else H.share_amax(candidate, cand2[r0:r0 + rows])
+                _, dest, _ = H.conv_nn(blk.view(1, rows, K), wp, B, 1, 1, res=dest, out=dest)
             dest = dest.view(ctx.shape)
         dcand = None
         if ctx.needs_input_grad[1]:
             # learnable candidates (DeepMel feature model): dcand_o = sum_b dscaled[b,o] est_b - coef_o cand_o
             estimate, scores, inv = ctx.saved_tensors[2:]
-            wpt = H.pack_weights(dscaled, 1, Bc, B, 1, 0, 1, Bc, 0, alpha=alpha, shape=(K, 1))
-            _, dcand, _ = H.conv_nn(estimate.view(1, B, K), wpt, Bc, 1, 1)
+            dcand = torch.empty(Bc, K, device=candidate.device, dtype=torch.float32)
+            for r0, rows in blocks:
+                wpt = H.pack_weights(dscaled.view(-1)[r0:], 1, rows, B, 1, 0, 1, Bc, 0, alpha=alpha, shape=(K, 1))
+                H.conv_nn(estimate.view(1, B, K), wpt, rows, 1, 1,
+                          out=dcand[r0:r0 + rows] if len(blocks) > 1 else dcand)
             coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
-            H.row_axpy_sub(dcand.view(Bc, K), candidate.view(Bc, K), coef)
+            H.row_axpy_sub(dcand, cand2, coef)
             dcand = dcand.view(ctx.cand_shape)
         return dest, dcand, None
 
@@ -300,7 +340,7 @@ def clip_scores(estimate, candidate, want_probs=False):
     B, Bc = estimate.shape[0], candidate.shape[0]
     K = estimate.numel() // B
     inv = H.clip_inv_norms(candidate)
-    part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+    part = _clip_raw_scores(estimate, candidate, B, Bc, K)
     scores, probs, _, _ = H.clip_ce(part, inv, want_probs=want_probs)
     return probs if want_probs else scores
 
@@ -312,7 +352,7 @@ def clip_forward_timed(estimate, candidate, inv, timer):
     K = estimate.numel() // B
     H.set_kernel_timer(timer)
     try:
-        part = H.gemm_nt_partials(estimate, candidate, 1, B, Bc, K, (0, K), (0, K))
+        part = _clip_raw_scores(estimate, candidate, B, Bc, K)
         return H.clip_ce(part, inv, want_grad=True, want_loss=True)
     finally:
         H.set_kernel_timer(None)

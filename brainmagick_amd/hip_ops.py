@@ -162,7 +162,7 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
     """An [AMAX_SHARDS] fp32 slot for a producer kernel to publish max|t| into (f16x2 mode only; None otherwise).
     Slots are carved out of pooled buffers, each slot is used once.  The slot is attached to the tensor like
     `amax()` would, so the consuming contraction finds it without a pass over the tensor."""
-    if _compute_dtype != "f16x2" or _NO_PUBLISH:
+    if _compute_dtype != "f16x2" or _NO_PUBLISH or t.numel() == 0:      # empty: the producer returns before it writes
         return None
     pool = _amax_pool.get(t.device)
     if pool is None or pool[1] >= pool[0].numel():
@@ -176,6 +176,28 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
 def _slot_args(slot):
     """(amax_out, amax_ws) arguments of a producer."""
     return (_p(slot), _p(_amax_ws(slot.device)) if slot is not None else None)
+
+
+def _touched(t: torch.Tensor) -> torch.Tensor:
+    """Called by every wrapper that lets a library kernel write INTO an existing tensor through its raw pointer:
+    torch's version counter does not see such writes, so a maximum published for the old contents must go."""
+    if getattr(t, "_bm_amax", None) is not None:
+        try:
+            del t._bm_amax
+        except AttributeError:
+            pass
+    return t
+
+
+def share_amax(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
+    """``view`` is a slice of ``src``: the maximum of the whole tensor bounds the slice (any upper bound within the
+    f16 headroom serves as the scale), so the slice needs no pass of its own."""
+    slot = amax(src)
+    try:
+        view._bm_amax = (view._version, view.data_ptr(), slot, False)
+    except Exception:
+        pass
+    return view
 
 
 # ------------------------------------------------------------------------------------------------
@@ -318,14 +340,22 @@ def pack_conv_dgrad(weight: torch.Tensor, shape=None) -> torch.Tensor:
 def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: int = 1,
             widx: tp.Optional[torch.Tensor] = None, bias=None, scale=None, shift=None, res=None,
             act: int = ACT_NONE, leak: float = 0., want_pre: bool = False, want_out: bool = True,
-            want_stats: bool = False):
-    """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T]."""
+            want_stats: bool = False, out: tp.Optional[torch.Tensor] = None):
+    """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T].  ``out``: write y_out there instead of
+    allocating (it may be ``res`` itself: every element is read and written by the same thread, which is how the
+    ClipLoss backward accumulates over candidate blocks)."""
     _req(x, "conv_nn.x")
     mode = getattr(wpacked, "_bm_mode", "f32")      # set by pack_weights
     _req(wpacked, "conv_nn.w", {"f32": torch.float32, "f16x2": torch.uint8}.get(mode, torch.bfloat16))
     B, Cin, T = x.shape
     y_pre = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_pre else None
-    y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
+    if out is not None:
+        _req(out, "conv_nn.out")
+        assert want_out and out.numel() == B * M * T, (out.shape, (B, M, T))
+        y_out = out
+        _touched(y_out)
+    else:
+        y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
     stats = None
     if want_stats:
         stats = torch.empty(lib().bm_conv_stats_tiles(B, T), M, 2, device=x.device,
@@ -379,7 +409,8 @@ def index_error_flag(device) -> torch.Tensor:
         device = torch.device("cuda", torch.cuda.current_device())
     flag = _index_err.get(device)
     if flag is None:
-        flag = torch.zeros(2, device=device, dtype=torch.int32)     # [index out of range, non-finite input]
+        # [index out of range, non-finite input, unsupported (not all-true) ClipLoss mask]
+        flag = torch.zeros(3, device=device, dtype=torch.int32)
         _index_err[device] = flag
     return flag
 
@@ -439,7 +470,9 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
     mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
     if mode == "f16x2":
-        contiguous = tuple(a_strides) == (M * T, T) and tuple(x_strides) == (Cn * T, T)
+        # rows T apart; the segment stride only matters when there is more than one segment
+        contiguous = a_strides[1] == T and x_strides[1] == T and \
+            (S == 1 or (a_strides[0] == M * T and x_strides[0] == Cn * T))
         if not (contiguous and lib().bm_gemm_nt_h2_covers(M, Cn, KS, S, T, G, dil, int(order is not None))):
             mode = "f32x3"      # shapes without a wide f16x2 kernel: the (equally fp32-accurate) 3 x bf16 kernels
         elif nsplit is None:
@@ -699,7 +732,7 @@ def row_axpy_sub(y: torch.Tensor, x: torch.Tensor, coef: torch.Tensor):
     rows = y.shape[0]
     check(lib().bm_row_axpy_sub(_p(y), _p(x), _p(_req(coef, "coef")), rows, y.numel() // max(rows, 1),
                                 _stream()), "bm_row_axpy_sub")
-    return y
+    return _touched(y)
 
 
 def center_scale(x: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
@@ -711,7 +744,7 @@ def center_scale(x: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
     _req(scale, "center_scale.scale")
     B, C, T = x.shape
     assert center.shape[-1] == C and scale.shape == center.shape
-    out = x if inplace else torch.empty_like(x)
+    out = _touched(x) if inplace else torch.empty_like(x)
     maxabs = torch.zeros(B, device=x.device, dtype=torch.float32) if want_maxabs else None
     check(lib().bm_center_scale(_p(x), _p(out), _p(_opt(group, "group", torch.int64)), _p(center),
                                 _p(scale), B, C, T, int(clip), float(limit), _p(maxabs), _stream()),

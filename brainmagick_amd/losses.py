@@ -28,6 +28,7 @@ class ClipLoss(torch.nn.Module):
         self.tmin_train = tmin_train
         self.tmax_train = tmax_train
         self.dset_args = dset_args
+        self.defer_mask_check = False       # brainmagick_amd.solver.Solver sets it (see forward)
 
     def trim_samples(self, estimates, candidates):
         """Crop both [B, C, T] tensors to the samples between (tmin, tmax) seconds, counted from
@@ -78,7 +79,13 @@ class ClipLoss(torch.nn.Module):
         negatives (losses.py:104-114).  ``target_offset`` (extension, default 0 = reference
         behaviour) shifts the targets to candidates [offset, offset+B): a data-parallel rank uses
         it to point at its own block of the whole-node gathered candidates."""
-        assert mask.all(), "mask is not supported for now"
+        if self.defer_mask_check and mask.is_cuda:
+            # Solver: the reference's assert costs a host sync in the middle of the step; the verdict is OR-ed into
+            # the device-side flag word and raised at the next step's single synchronisation point
+            from . import hip_ops as H
+            H.index_error_flag(mask.device)[2:3].bitwise_or_((~mask.all()).to(torch.int32).view(1))
+        else:
+            assert mask.all(), "mask is not supported for now"
         assert estimate.size(0) + target_offset <= candidate.size(0), \
             "need at least as many targets as estimates"
         estimate, candidate = self._prepare(estimate, candidate)

@@ -14,8 +14,12 @@ one (foreach) kernel chain; here all parameters and all gradients live in ONE fl
 checkpoint code (bm/solver.py:64,115-117 -- ``self.optimizer.state_dict()`` goes into the flashy
 checkpoint) works unchanged and optimizer checkpoints are interchangeable with the reference:
 ``state[p] = {step, exp_avg, exp_avg_sq}`` where the moments are VIEWS into the flat buffers.
-In a data-parallel run every rank only updates the moments of its own shard; ``state_dict()``
-all-gathers the shards first so that the checkpoint written by rank 0 is complete.
+In a data-parallel run every rank only updates the moments of its own shard.  ``state_dict()`` never
+communicates (checkpoint code usually calls it on rank 0 only -- a hidden all-gather there would hang or,
+worse, pair up with the other ranks' next reduce-scatter): EVERY rank calls ``gather_moments()`` (a
+collective; ``Solver.state_dict()`` does) before any rank saves, and ``state_dict()`` raises while the
+moments are still sharded.  ``distrib.sharded_step(..., shard=False)`` (or ``BM_SHARD_OPTIMIZER=0``) keeps
+the full moments on every rank instead (all-reduce + full Adam), for code that cannot add that call.
 """
 import typing as tp
 
@@ -139,7 +143,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     def gather_moments(self):
         """Data-parallel runs: make ``exp_avg`` / ``exp_avg_sq`` complete on every rank (each rank
-        owns the moments of its shard only).  No-op for a single process."""
+        owns the moments of its shard only).  COLLECTIVE: every rank calls it (two in-place all-gathers),
+        e.g. at the end of an epoch right before the checkpoint.  No-op for a single process."""
         from . import distrib
         if self._moments_sharded and distrib.is_distributed():
             distrib.all_gather_shards(self.exp_avg)
@@ -147,8 +152,14 @@ class FlatAdam(torch.optim.Optimizer):
         self._moments_sharded = False
 
     def state_dict(self):
-        """torch.optim.Adam layout; moments are cloned (a checkpoint must not alias the live buckets)."""
-        self.gather_moments()
+        """torch.optim.Adam layout; moments are cloned (a checkpoint must not alias the live buckets).
+        Never communicates: raises while a data-parallel run's moments are still sharded."""
+        from . import distrib
+        if self._moments_sharded and distrib.is_distributed() and distrib.world_size() > 1:
+            raise RuntimeError(
+                "FlatAdam.state_dict(): the Adam moments are sharded over the ranks (ZeRO-1); call "
+                "optimizer.gather_moments() on EVERY rank first (Solver.state_dict() does), or run "
+                "distrib.sharded_step(..., shard=False) / BM_SHARD_OPTIMIZER=0")
         state = {}
         for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             k = p.numel()

@@ -230,6 +230,7 @@ int bm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * the library owns; fp32 buffers; collectives are enqueued on `stream`, never synchronised; NCCL in-place
  * conventions (all-gather: send == recv + rank*count; reduce-scatter: recv == send + rank*count). */
 int bm_comm_unique_id_bytes(void);
+int bm_comm_available(void);                              /* 0 = librccl loads and has every symbol (local check) */
 int bm_comm_unique_id(void* out_id);                       /* rank 0; the host hands the bytes to the others */
 int bm_comm_init(const void* id, int world, int rank, int device, void** handle);
 int bm_comm_destroy(void* handle);

@@ -256,6 +256,99 @@ def scale_reject_fixture():
     return out
 
 
+
+def _extract_function(path, name):
+    """Source of the top-level function `name` of a reference file, taken from its AST (the module itself cannot
+    be imported: it pulls flashy / dora / mne)."""
+    import ast
+    text = Path(path).read_text()
+    for node in ast.parse(text).body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            return ast.get_source_segment(text, node), node, text
+    raise KeyError(name)
+
+
+def retrieval_fixture(losses):
+    """The retrieval rules as the reference computes them, executed from the reference sources:
+      * scripts/run_eval_probs.py:237-264 `_get_accuracy_from_probs` (a pure function: compiled as is);
+      * bm/wer.py:82-121, the per-segment loop of `get_wer` from `negatives = negatives.to(solver.device)` to the
+        metrics dict, run statement by statement under a stub `solver` (device "cpu", the reference ClipLoss,
+        `args.test.wer_topx`), with `LogProgress` = identity."""
+    import ast
+    import types
+    REF = Path("/root/reference")
+    gen = torch.Generator().manual_seed(77)
+    # --- segment / vocabulary accuracy -----------------------------------------------------------------
+    src, _, _ = _extract_function(REF / "scripts" / "run_eval_probs.py", "_get_accuracy_from_probs")
+    ns = {"torch": torch}
+    exec(compile(src, "run_eval_probs._get_accuracy_from_probs", "exec"), ns)
+    acc_fn = ns["_get_accuracy_from_probs"]
+    Bq, V = 96, 150
+    probs = torch.softmax(2.0 * torch.randn(Bq, V, generator=gen), dim=1)
+    vocab_labels = torch.randint(0, 60, (V,), generator=gen)           # several columns share a label
+    target_labels = vocab_labels[torch.randint(0, V, (Bq,), generator=gen)].clone()
+    target_labels[:7] = 1000                                             # labels no column carries
+    for b in range(Bq):                                                  # make the targets partly retrievable
+        if b % 3 == 0:
+            cols = (vocab_labels == target_labels[b]).nonzero().flatten()
+            if len(cols):
+                probs[b, cols[0]] += 0.05
+    probs = probs / probs.sum(1, keepdim=True)
+    out = {"acc/probs": probs.numpy().copy(), "acc/vocab_labels": vocab_labels.numpy().copy(),
+           "acc/target_labels": target_labels.numpy().copy()}
+    for k in (1, 5, 10):
+        out[f"acc/top{k}"] = np.array(acc_fn(probs, target_labels, vocab_labels, topk=k))
+    # --- word-level WER loop -----------------------------------------------------------------------------
+    N, Fd, T, n_neg, topx, seed = 60, 6, 20, 32, 3, 11
+    estimates = torch.randn(N, Fd, T, generator=gen)
+    outputs = 0.12 * estimates + torch.randn(N, Fd, T, generator=gen)    # estimates carry SOME signal about their target
+    word_hashes = torch.randint(1, 19, (N,), generator=gen).int()        # 18 words: duplicates among negatives
+    kept = torch.randperm(N, generator=torch.Generator().manual_seed(seed))[:n_neg]
+    _, fn_node, text = _extract_function(REF / "bm" / "wer.py", "get_wer")
+    body = fn_node.body
+    first = next(i for i, st in enumerate(body)
+                 if isinstance(st, ast.Assign) and ast.get_source_segment(text, st).startswith("negatives = negatives.to("))
+    last = next(i for i, st in enumerate(body)
+                if isinstance(st, ast.Assign) and ast.get_source_segment(text, st).startswith("metrics ="))
+    import textwrap
+    loop_src = "\n".join(textwrap.dedent(" " * st.col_offset + ast.get_source_segment(text, st))
+                         for st in body[first:last + 1])
+    solver = types.SimpleNamespace(
+        device="cpu", loss=losses.ClipLoss(),
+        args=types.SimpleNamespace(num_prints=1, test=types.SimpleNamespace(wer_topx=topx, wer_random=False)))
+    env = {"torch": torch, "solver": solver, "ClipLoss": losses.ClipLoss, "logger": None,
+           "LogProgress": lambda logger, it, **kw: it, "estimates": estimates, "outputs": outputs,
+           "word_hashes": word_hashes, "negatives": outputs[kept], "negative_hashes": word_hashes[kept]}
+    exec(compile(loop_src, "bm/wer.py:get_wer[loop]", "exec"), env)
+    out.update({"wer/estimates": estimates.numpy().copy(), "wer/outputs": outputs.numpy().copy(),
+                "wer/word_hashes": word_hashes.numpy().copy(), "wer/kept": kept.numpy().copy(),
+                "wer/wer": np.array(env["metrics"]["wer"]), "wer/wer_vocab": np.array(env["metrics"]["wer_vocab"]),
+                "wer/meta": np.array(json.dumps(dict(n_negatives=n_neg, topx=topx, perm_seed=seed)))})
+    return out
+
+
+def mne_layout_fixture(common):
+    """bm/models/common.py:190-222 `PositionGetter.get_recording_layout`, the branch real recordings take, under
+    a stub `mne.find_layout` that returns a layout object of the shape mne's has (`names`, `pos` [n, 4] float64):
+    channel names with the '-<id>' suffix of CTF/KIT files, two channels the layout does not know, layout rows in
+    a different order than the recording's channels."""
+    import types
+    gen = np.random.default_rng(5)
+    n_layout = 30
+    names = [f"MEG {k:03d}" for k in range(n_layout)]
+    order = gen.permutation(n_layout)
+    layout = types.SimpleNamespace(names=[names[k] for k in order],
+                                   pos=np.concatenate([gen.uniform(-0.4, 0.55, (n_layout, 2)),
+                                                       np.full((n_layout, 2), 0.04)], axis=1))
+    ch_names = [f"MEG {k:03d}-4507" for k in range(26)] + ["UADC001-4507", "MEG 027", "STIM-1", "MEG 029-12"]
+    info = types.SimpleNamespace(ch_names=ch_names)
+    common.mne.find_layout = lambda _info: layout
+    rec = types.SimpleNamespace(recording_index=3, mne_info=info, study_name=lambda: "stub", recording_uid="stub_0")
+    positions = common.PositionGetter().get_recording_layout(rec)
+    return {"layout_names": np.array(layout.names), "layout_pos": layout.pos.copy(),
+            "ch_names": np.array(ch_names), "positions": positions.numpy().copy()}
+
+
 def main():
     np.savez_compressed(HERE / "scale_reject.npz", **scale_reject_fixture())
     print("scale_reject: done")
@@ -266,6 +359,10 @@ def main():
         print(f"{name}: losses={out['out/losses']}")
     np.savez_compressed(HERE / "clip_loss.npz", **clip_only_fixture(losses))
     print("clip_loss: done")
+    np.savez_compressed(HERE / "retrieval_rules.npz", **retrieval_fixture(losses))
+    print("retrieval_rules: done")
+    np.savez_compressed(HERE / "mne_layout.npz", **mne_layout_fixture(common))
+    print("mne_layout: done")
 
 
 if __name__ == "__main__":

@@ -138,6 +138,60 @@ def test_dynamic_range_is_handled_by_the_scales(h2_mode, H, xs, ws):
     assert err.max().item() < FWD_TOL, err.max().item()
 
 
+# ---- per-channel dynamic range INSIDE one activation / gradient tensor ----------------------------------------
+# Activations carry ONE power-of-two scale per tensor (their maximum lands in [2^14, 2^15) of the f16 range).  A value
+# v keeps 22 significant bits while |v| >= 2^-16 max|tensor|; below that its low plane sinks into the f16
+# subnormals (spacing 2^-24 in scaled units) and the ABSOLUTE error stays <= 2^-39 max|tensor|.
+#  * conv: a channel-wise relative bound holds whenever an output channel is not fed EXCLUSIVELY by inputs that are
+#    more than 2^-16 below the tensor maximum: |err(y[m])| <= 2^-38 max|x| sum|w[m]| + the fp32 accumulation error;
+#  * weight gradient: dW row m only sees dy channel m (and column c only x channel c), so a channel d decades below
+#    its tensor's maximum has row-wise relative error <= max(fp32-class, 2^-37 * 10^d).  Rows within 2^-16 of the
+#    maximum -- 4.8 decades; BatchNorm'ed activations and their gradients span one or two -- are fp32-class.
+H2_ABS = 2.0 ** -37
+
+
+@pytest.mark.parametrize("decades", [0, 2, 4, 6, 8])
+def test_per_channel_spread_weight_gradient_rows(h2_mode, H, decades):
+    g = _gen(40 + decades)
+    B, Cin, M, KS, dil, T = 4, 128, 320, 3, 2, 256
+    sdy = torch.logspace(0, -decades, M)
+    sx = torch.logspace(0, -decades, Cin)
+    dy = torch.randn(B, M, T, generator=g) * sdy[None, :, None]
+    x = torch.randn(B, Cin, T, generator=g) * sx[None, :, None]
+    assert H.lib().bm_gemm_nt_h2_covers(M, Cin, KS, B, T, 1, dil, 0)
+    dw = H.gemm_nt(dy.cuda(), x.cuda(), B, M, Cin, T, KS, dil)[0].double().cpu()
+    ref = _wgrad_ref(dy, x, KS, dil)
+    assert rel_l2(dw, ref) < 1e-6                                     # norm-wise: always fp32-class
+    row_err = (dw - ref).norm(dim=(1, 2)) / ref.norm(dim=(1, 2))      # per dy channel
+    col_err = (dw - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))      # per x channel
+    row_bound = torch.clamp(H2_ABS / sdy.double(), min=2e-6)
+    col_bound = torch.clamp(H2_ABS / sx.double(), min=2e-6)
+    print(f"spread 1e-{decades}: worst dW row {row_err.max():.2e}, column {col_err.max():.2e} "
+          f"(rows within 2^-16 of the maximum: {row_err[sdy >= 2.0 ** -16].max():.2e})")
+    assert bool((row_err <= row_bound).all()), (row_err / row_bound).max().item()
+    assert bool((col_err <= col_bound).all()), (col_err / col_bound).max().item()
+    assert row_err[sdy >= 2.0 ** -16].max().item() < 2e-6 and col_err[sx >= 2.0 ** -16].max().item() < 2e-6
+
+
+@pytest.mark.parametrize("decades", [0, 4, 8])
+def test_per_channel_spread_conv_output_channels(h2_mode, H, decades):
+    g = _gen(50 + decades)
+    B, Cin, M, KS, dil, T = 3, 128, 320, 3, 2, 256
+    sx = torch.logspace(0, -decades, Cin)
+    x = torch.randn(B, Cin, T, generator=g) * sx[None, :, None]
+    w = torch.randn(M, Cin, KS, generator=g) / math.sqrt(Cin * KS)
+    w[M // 2:, :Cin // 2] = 0                     # the second half of the outputs only reads the SMALL channels
+    ref = F.conv1d(x.double(), w.double(), None, padding=dil, dilation=dil)
+    _, y, _ = H.conv_nn(x.cuda(), H.pack_conv_fwd(w.cuda(), (T, dil)), M, KS, dil)
+    err = (y.double().cpu() - ref).abs().amax(dim=(0, 2))                               # per output channel
+    # absolute bound of the split + fp32-class relative term on the channel's own magnitude
+    bound = 2.0 ** -38 * x.abs().max().double() * w.double().abs().sum(dim=(1, 2)) + 3e-6 * ref.abs().amax(dim=(0, 2))
+    rel = (y.double().cpu() - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))
+    print(f"spread 1e-{decades}: worst output channel rel-L2 {rel.max():.2e} (first half {rel[:M // 2].max():.2e})")
+    assert bool((err <= bound).all()), (err / bound).max().item()
+    assert rel[:M // 2].max().item() < FWD_TOL     # channels fed by the large inputs: plain fp32 tolerance
+
+
 def test_nonfinite_inputs_do_not_turn_finite(h2_mode, H):
     g = _gen(3)
     x = torch.randn(1, 32, 200, generator=g)

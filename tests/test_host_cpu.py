@@ -356,3 +356,161 @@ def test_pack_plan_refresh_and_eviction_logic(monkeypatch):
         plan.get(params[0], geom)
         plan.get(params[1], geom)
     assert stub.batches[-1][0] == 2 and len(plan.entries) == 2
+
+
+def test_loopback_communicator_runs_the_data_parallel_exchange_in_process():
+    """tests/loopback.py (N replicas as threads of one process, the stand-in for ranks on the 1-GPU test box) against
+    the same expectations as the 2-process gloo test: sharded step == mean-gradient Adam, rank-ordered candidate
+    gather, buffer averaging, moment gather -- here at world 2 and 3, with and without optimizer sharding."""
+    from loopback import run_replicas
+    from brainmagick_amd import distrib
+
+    class CpuFlatAdam:
+        def __init__(self, n, pad_to):
+            self.padded = (n + pad_to - 1) // pad_to * pad_to
+            g = torch.Generator().manual_seed(0)
+            self.flat_param = torch.randn(self.padded, generator=g)
+            self.flat_grad = torch.zeros(self.padded)
+            self.m = torch.zeros(self.padded)
+            self.v = torch.zeros(self.padded)
+            self.t = 0
+
+        def step(self, shard=None, grad_scale=1.0):
+            self.t += 1
+            lo, hi = shard if shard else (0, self.padded)
+            O.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi] * grad_scale, self.m[lo:hi], self.v[lo:hi],
+                        self.t)
+
+    for world in (2, 3):
+        for shard in (True, False):
+            def body(r):
+                assert distrib.is_distributed() and distrib.world_size() == world and distrib.rank() == r
+                opt = CpuFlatAdam(1001, pad_to=world * 4)
+                for it in range(3):
+                    g = torch.Generator().manual_seed(100 * it + r)
+                    opt.flat_grad.copy_(torch.randn(opt.padded, generator=g))
+                    distrib.sharded_step(opt, shard=shard)
+                gather = distrib.CandidateGather()
+                gather.start(torch.full((3, 2, 5), float(r)))
+                out, off = gather.wait()
+                assert off == 3 * r and all(bool((out[3 * k:3 * k + 3] == k).all()) for k in range(world))
+                bn = torch.nn.BatchNorm1d(4)
+                bn.running_mean.fill_(float(r))
+                bucket = distrib.BufferBucket([bn])
+                bucket.average()
+                assert torch.allclose(bn.running_mean, torch.full((4,), (world - 1) / 2))
+                distrib.all_gather_shards(opt.m)
+                assert abs(distrib.max_over_ranks(float(r)) - (world - 1)) < 1e-9
+                return opt.flat_param.clone(), opt.m.clone()
+
+            res = run_replicas(world, body)
+            ref = CpuFlatAdam(1001, pad_to=world * 4)
+            for it in range(3):
+                grads = [torch.randn(ref.padded, generator=torch.Generator().manual_seed(100 * it + k))
+                         for k in range(world)]
+                ref.flat_grad.copy_(O.sync_gradients_reference([[g] for g in grads])[0])
+                ref.step()
+            for p, m in res:
+                assert torch.allclose(p, ref.flat_param, rtol=1e-6, atol=1e-7)
+                assert torch.allclose(m, ref.m, rtol=1e-5, atol=1e-8)      # gathered moments are complete
+            assert torch.equal(res[0][0], res[-1][0])                      # replicas stay bit-identical
+    assert distrib.comm() is None and not distrib.is_distributed()
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` outside torchrun re-launches itself as the driver would launch it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd, env = bench.self_launch_command(8, ["--gpus", "8", "--steps", "5"], port=29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    assert cmd[-5] == str(ROOT / "bench.py") and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "RANK" not in env
+    cmd2, _ = bench.self_launch_command(2, [])
+    assert 1024 < int(cmd2[cmd2.index("--master-port") + 1]) < 65536
+
+
+TORCHRUN_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from brainmagick_amd import distrib
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"       # what torch.distributed.run exports
+# the unique-id exchange of the RCCL communicator (distrib._RcclComm) through the launcher's store
+store = distrib._rendezvous_store(rank, world)
+assert distrib._all_ranks_ok(store, "t/loaded", rank, world, True)
+assert not distrib._all_ranks_ok(store, "t/one_failed", rank, world, rank != 1)    # agreed by EVERY rank
+if rank == 0:
+    store.set("t/id", bytes(range(128)))
+assert bytes(store.get("t/id")) == bytes(range(128))
+# fallback communicator on the SAME store (no second rendezvous on MASTER_PORT)
+distrib._comm = distrib._TorchComm("gloo", store=store)
+assert distrib.is_distributed() and distrib.world_size() == world and distrib.rank() == rank
+t = torch.tensor([float(rank + 1)])
+distrib.comm().all_reduce(t)
+assert float(t) == 3.0
+distrib.barrier()
+distrib.shutdown()
+print("TORCHRUN_WORKER_OK", rank, flush=True)
+'''
+
+
+def test_rendezvous_under_torch_distributed_run(tmp_path):
+    """The launch the driver uses (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P`): the agent's TCP store carries the communicator's unique id and the agreement on
+    the communicator kind, and the torch.distributed fallback joins through the same store."""
+    import socket
+    script = tmp_path / "torchrun_worker.py"
+    script.write_text(TORCHRUN_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(ROOT)],
+                         env=env, capture_output=True, text=True, timeout=240)
+    # (the two ranks share stdout: their lines may interleave)
+    assert out.returncode == 0 and out.stdout.count("TORCHRUN_WORKER_OK") == 2, out.stdout + out.stderr
+
+
+def test_adopts_a_process_group_somebody_else_initialised(tmp_path):
+    """INTEGRATION.md §4: a maintainer who keeps `flashy.distrib.init()` (= torch.distributed.init_process_group,
+    bm/train.py:139) and only swaps `sharded_step` in must still get the gradient exchange."""
+    worker = tmp_path / "adopt_worker.py"
+    worker.write_text(r'''
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+dist.init_process_group("gloo")                      # NOT brainmagick_amd.distrib.init()
+from brainmagick_amd import distrib
+assert distrib.comm() is None
+assert distrib.is_distributed() and distrib.world_size() == 2 and distrib.rank() == dist.get_rank()
+assert distrib.comm_kind() == "torch.distributed/gloo"
+class Opt:
+    def __init__(self):
+        self.flat_param = torch.zeros(8); self.flat_grad = torch.full((8,), float(dist.get_rank() + 1)); self.padded = 8
+        self.calls = []
+    def step(self, shard=None, grad_scale=1.0):
+        self.calls.append((shard, grad_scale))
+        lo, hi = shard
+        self.flat_param[lo:hi] -= self.flat_grad[lo:hi] * grad_scale
+opt = Opt()
+distrib.sharded_step(opt)
+assert opt.calls == [((4 * dist.get_rank(), 4 * dist.get_rank() + 4), 0.5)]
+assert torch.equal(opt.flat_param, torch.full((8,), -1.5)), opt.flat_param     # mean of 1 and 2, all shards gathered
+print("ADOPT_OK", dist.get_rank(), flush=True)
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, str(worker), str(ROOT)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ADOPT_OK {r}" in out, out

@@ -417,6 +417,27 @@ def test_word_level_wer_batched(H, n_neg):
 
 
 @pytest.mark.gpu
+def test_retrieval_rules_against_reference_fixture(H):
+    """The batched GPU retrieval evaluation against numbers produced by the reference's own functions
+    (scripts/run_eval_probs.py:237-264, bm/wer.py:82-121 executed from source: tests/golden/retrieval_rules.npz)."""
+    import json
+    from helpers import Golden
+    from brainmagick_amd import retrieval
+    from brainmagick_amd.losses import ClipLoss
+    g = Golden("retrieval_rules")
+    probs = g.t("acc/probs").cuda()
+    for k in (1, 5, 10):
+        got = retrieval.get_accuracy_from_probs(probs, g.t("acc/target_labels"), g.t("acc/vocab_labels"), topk=k)
+        assert got == pytest.approx(float(g.raw[f"acc/top{k}"]), abs=1e-9)
+    meta = json.loads(str(g.raw["wer/meta"]))
+    gen = torch.Generator().manual_seed(meta["perm_seed"])
+    got = retrieval.get_wer(ClipLoss().cuda(), g.t("wer/estimates"), g.t("wer/outputs"), g.t("wer/word_hashes"),
+                            n_negatives=meta["n_negatives"], topx=meta["topx"], generator=gen, batch_size=16)
+    assert got["wer"] == pytest.approx(float(g.raw["wer/wer"]), abs=1e-9)
+    assert got["wer_vocab"] == pytest.approx(float(g.raw["wer/wer_vocab"]), abs=1e-9)
+
+
+@pytest.mark.gpu
 def test_wide_and_narrow_f32x3_kernels_agree(tmp_path):
     """The wide-tile kernels (conv_nn_x3w / gemm_nt_x3w) and the 160x128 / 64x64 ones they replace for the
     big layers are two implementations of the same fp32-accurate contraction: run the same conv forward,

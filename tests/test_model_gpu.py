@@ -19,15 +19,18 @@ LOSS_TOL = 1e-4
 
 
 NOISE = 1e-6
+PARITY_NOISE = 3.0      # planted-noise level of the long-horizon parity run (calibrated: top-10 far from 0 % and 100 %)
 
 
 def close(a, b, tol, ref_scale):
-    """rel-L2 <= tol, or -- for gradients that are analytically zero (the conv bias in front of a
-    BatchNorm: sum(dy) == 0) and hence pure round-off noise in the reference as well --
-    max|a-b| <= 1e-6 x the largest gradient norm of the model."""
+    """rel-L2 <= tol.  The only escape is for gradients that are round-off noise IN THE REFERENCE (analytically zero:
+    the conv bias in front of a BatchNorm has sum(dy) == 0; recognised by max|g_ref| <= 1e-5 x the largest gradient
+    norm of the model): there max|a-b| <= 1e-6 x that norm.  A parameter with a small but genuine gradient gets no
+    absolute escape -- it has to meet the relative tolerance on its own norm."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return (a - b).norm().item() <= tol * b.norm().item() or \
-        (a - b).abs().max().item() <= NOISE * ref_scale
+    if (a - b).norm().item() <= tol * b.norm().item():
+        return True
+    return is_noise_grad(b, ref_scale) and (a - b).abs().max().item() <= NOISE * ref_scale
 
 
 def is_noise_grad(g, ref_scale):
@@ -504,21 +507,155 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible(tmp_path):
         assert p.returncode == 0 and f"TWO_RANK_OK {r}" in out, out
 
 
+@pytest.mark.parametrize("negatives", ["local", "node"])
+def test_two_replicas_match_the_data_parallel_oracle(negatives):
+    """SURVEY.md §8(c) data-parallel oracle against the HIP path at world size 2 on ONE GPU: two `Solver` replicas
+    run the unmodified `train_step` in two threads under an in-process loopback communicator (tests/loopback.py:
+    the same interface as the RCCL communicator -- candidate all-gather + target_offset, in-place reduce-scatter
+    of the flat gradient bucket, sharded Adam, in-place all-gather of the parameters, buffer all-reduce).
+    Expectation = the oracle run once per rank on that rank's batch ("node": against the candidates of BOTH
+    ranks, own block as targets), gradients averaged over the ranks (flashy.distrib.sync_model, bm/solver.py:386),
+    one Adam step on the mean, BatchNorm running statistics averaged, per-rank batch statistics.  Then a
+    checkpoint (`Solver.state_dict()`, which gathers the sharded Adam moments) is loaded into fresh replicas that
+    must continue bit-identically."""
+    from loopback import run_replicas
+    from brainmagick_amd import distrib
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.solver import Solver
+    world, B, steps = 2, 8, 2
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=64, merger_channels=96, initial_linear=96, depth=4, merger_dropout=0.0)
+    C, T, Fd, S, hidden = 30, 160, 12, 4, 96
+
+    def build():
+        torch.manual_seed(0)
+        return SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
+
+    sd0 = copy.deepcopy(build().state_dict())
+    batches = [[synthetic.make_batch(B, C, T, Fd, S, seed=50 + 10 * r + k, n_layouts=2) for k in range(steps + 1)]
+               for r in range(world)]
+
+    def body(r):
+        assert distrib.is_distributed() and distrib.world_size() == world and distrib.rank() == r
+        model = build()
+        solver = Solver(model, negatives=negatives)
+        names = [k for k, _ in model.named_parameters()]
+        lo, hi = distrib.shard_bounds(solver.optimizer.padded, world, r)
+        out = dict(losses=[], names=names, offsets=list(solver.optimizer.offsets), shard=(lo, hi))
+        for k in range(steps):
+            out["losses"].append(float(solver.train_step(batches[r][k])))
+            if k == 0:
+                out["grad_shard"] = solver.optimizer.flat_grad[lo:hi].clone().cpu()      # sum over the ranks
+        out["flat_param"] = solver.optimizer.flat_param.clone().cpu()
+        out["sd"] = {k: v.clone().cpu() for k, v in model.state_dict().items()}
+        with pytest.raises(RuntimeError, match="gather_moments"):
+            solver.optimizer.state_dict()             # sharded moments: no hidden collective, a loud error
+        state = copy.deepcopy(solver.state_dict())    # collective: every replica calls it
+        out["exp_avg"] = state["optimizer"]["state"][0]["exp_avg"].clone().cpu()
+        nxt = float(solver.train_step(batches[r][steps]))
+        resumed = Solver(build(), negatives=negatives)
+        resumed.load_state_dict(state)
+        nxt2 = float(resumed.train_step(batches[r][steps]))
+        assert nxt == nxt2, (nxt, nxt2)
+        assert torch.equal(solver.optimizer.flat_param, resumed.optimizer.flat_param)
+        assert torch.equal(solver._buffers.flat, resumed._buffers.flat)
+        return out
+
+    res = run_replicas(world, body)
+    assert torch.equal(res[0]["flat_param"], res[1]["flat_param"]), "replicas diverged"
+    assert torch.equal(res[0]["exp_avg"], res[1]["exp_avg"]), "gathered moments differ between ranks"
+
+    # the data-parallel oracle
+    oracles = [O.OracleModel(copy.deepcopy(sd0), cfg, hidden, Fd) for _ in range(world)]
+    for k in range(steps):
+        per_rank = []
+        for r in range(world):
+            sb = batches[r][k]
+            cands = sb.features
+            if negatives == "node":
+                cands = torch.roll(torch.cat([batches[q][k].features for q in range(world)]), -r * B, 0)
+            loss, _, grads = oracles[r].loss_and_grads(sb.meg, sb.positions(), sb.subject_index, cands, True)
+            assert abs(res[r]["losses"][k] - float(loss)) < LOSS_TOL, (k, r, res[r]["losses"][k], float(loss))
+            per_rank.append(grads)
+        mean = {n: sum(g[n] for g in per_rank) / world for n in per_rank[0]}
+        if k == 0:
+            gscale = max(v.double().norm().item() for v in mean.values())
+            for r in range(world):
+                flat = torch.zeros(res[r]["shard"][1] - res[r]["shard"][0] + res[r]["shard"][0], dtype=torch.float64)
+                full = torch.zeros(max(res[r]["offsets"]) + 10 ** 6, dtype=torch.float64)
+                for n, off in zip(res[r]["names"], res[r]["offsets"]):
+                    full[off:off + mean[n].numel()] = mean[n].reshape(-1).double()
+                lo, hi = res[r]["shard"]
+                assert rel_l2(res[r]["grad_shard"] / world, full[lo:hi]) < GRAD_TOL
+                del flat
+        for r in range(world):
+            oracles[r].apply_adam(mean)
+        for n in oracles[0].sd:                         # flashy sync_model averages the float buffers
+            if "running_" in n:
+                avg = sum(o.sd[n] for o in oracles) / world
+                for o in oracles:
+                    o.sd[n] = avg.clone()
+    for n, v in res[0]["sd"].items():
+        if not v.is_floating_point():
+            assert int(v) == int(oracles[0].sd[n]), n
+        elif n in mean:
+            if is_noise_grad(mean[n], gscale):
+                continue
+            ok, info = adam_params_close(v, oracles[0].sd[n], steps, mean[n], gscale)
+            assert ok, (n, info)
+        else:
+            assert running_stat_close(v, oracles[0].sd[n], steps), n
+
+
+# Dimensions of the long-horizon parity runs (this test and bench.py's `retrieval_parity`): every contraction of the
+# step runs in the SAME kernels as the headline benchmark -- the wide f16x2 conv (T > 128, M >= 96), the wide f16x2
+# weight gradients (M a multiple of 256 / 320 within 25 %, Cn of 64) and the f16x2 score contraction (batch >= 128);
+# like at full size, only the grouped (per-subject / per-layout) weight gradients, the layout logits and the
+# narrow-M final-layer weight gradient run in the 3 x bf16 kernels.
+PARITY_DIMS = dict(C=64, T=192, F=128, S=4, B=128, hidden=256, merger_channels=256, depth=4)
+
+
+def parity_model_cfg():
+    cfg = dict(O.CLIP_CONV_CFG)
+    d = PARITY_DIMS
+    cfg.update(merger_pos_dim=128, merger_channels=d["merger_channels"], initial_linear=d["merger_channels"],
+               depth=d["depth"], merger_dropout=0.0)
+    return cfg
+
+
+def assert_headline_kernels(names):
+    """`names`: labels of every MFMA launch of one training step (hip_ops.KernelTimer).  All convs, the dense weight
+    gradients and the score contraction must be the wide f16x2 kernels; the 3 x bf16 family may only appear for
+    the shapes it also serves in the headline run."""
+    convs = [n for n in names if n.startswith("conv_nn")]
+    assert convs and all(n.startswith("conv_nn_h2w_kernel") for n in convs), sorted(set(convs))
+    assert "clip_scores:gemm_nt_h2w" in names, sorted(set(names))
+    wide_wgrads = [n for n in names if n.startswith("gemm_nt_h2w_kernel")]
+    narrow = [n for n in names if n.startswith("gemm_nt_x3_kernel")]
+    d = PARITY_DIMS
+    n_dense = d["depth"] + d["depth"] // 2 + 2        # k3 convs + GLU convs + initial linear + head 1x1
+    assert len(wide_wgrads) >= n_dense, (len(wide_wgrads), n_dense, sorted(set(names)))
+    # merger logits, merger d(weights), subject layers, final 1x1 (M = F): the same four as at full size
+    assert len(narrow) <= 4, narrow
+    assert not [n for n in names if "_x3w" in n or n.startswith("gemm_nt_kernel") or "bf16" in n], names
+
+
 def test_training_curve_and_top10_parity():
-    """SURVEY.md §8d accuracy parity: train the same initial state for 200 steps on the same learnable
-    (planted-latent) batches with the HIP path and with the oracle; the loss curves must agree within
-    1 % (relative, every step) and the top-10 / top-1 segment-retrieval accuracy on 2 048 held-out
-    segments within +-1 point of each other.  The planted noise (0.8) keeps the task far from
-    saturation -- the oracle lands at ~52 % top-10 / ~20 % top-1 (chance 0.5 %) -- so that a precision
+    """SURVEY.md §8d accuracy parity THROUGH THE HEADLINE KERNELS: train the same initial state for 200 steps on the
+    same learnable (planted-latent) batches with the HIP path and with the oracle; the loss curves must agree
+    within 1 % (relative, every step) and the top-10 / top-1 segment-retrieval accuracy on 2 048 held-out segments
+    within +-1 point of each other.  The planted noise keeps the task away from saturation so that a precision
     regression of the HIP path would move the number."""
+    from brainmagick_amd import hip_ops as H
     from brainmagick_amd.models import SimpleConv
     from brainmagick_amd.solver import Solver
     from brainmagick_amd.losses import ClipLoss
     from brainmagick_amd import retrieval
-    cfg = dict(O.CLIP_CONV_CFG)
-    cfg.update(merger_pos_dim=128, merger_channels=32, initial_linear=32, depth=6,
-               merger_dropout=0.0)
-    C, T, Fd, S, B, hidden, steps, n_batches, n_held, noise = 24, 96, 16, 4, 32, 48, 200, 32, 2048, 0.8
+    assert H.get_compute_dtype() == "f16x2"
+    cfg = parity_model_cfg()
+    d = PARITY_DIMS
+    C, T, Fd, S, B, hidden = d["C"], d["T"], d["F"], d["S"], d["B"], d["hidden"]
+    steps, n_batches, n_held, noise = 200, 16, 2048, PARITY_NOISE
     torch.manual_seed(5)
     model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden},
                        n_subjects=S, **cfg)
@@ -526,23 +663,37 @@ def test_training_curve_and_top10_parity():
     solver = Solver(model)
     batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True, noise=noise)
                for i in range(n_batches)]
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, prev_threads))       # the GPU box's 256 hardware threads slow torch's CPU pool down
     hip_losses, ref_losses = [], []
-    for step in range(steps):
-        sb = batches[step % len(batches)]
-        hip_losses.append(float(solver.train_step(sb)))
-        ref_losses.append(float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index,
-                                                  sb.features)[0]))
-    hip, ref = torch.tensor(hip_losses), torch.tensor(ref_losses)
-    assert ref[-8:].mean() < 0.5 * ref[:8].mean(), "planted task should be learnable"
-    assert ((hip - ref).abs() / ref.abs()).max().item() < 1e-2, (hip_losses[-5:], ref_losses[-5:])
-    held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
-    est_hip, cand = solver.predict(held)
-    est_ref = oracle.forward(held.meg, held.positions(), held.subject_index)
-    acc_hip = retrieval.segment_topk_accuracy(ClipLoss().cuda(), est_hip, cand, topks=(1, 10))
-    probs_ref = O.clip_probabilities(est_ref, held.features)
+    try:
+        for step in range(steps):
+            sb = batches[step % len(batches)]
+            if step in (0, steps - 1):                     # which kernels ran, first and last step
+                timer = H.KernelTimer()
+                H.set_kernel_timer(timer)
+            hip_losses.append(float(solver.train_step(sb)))
+            if step in (0, steps - 1):
+                H.set_kernel_timer(None)
+                assert_headline_kernels([r[0] for r in timer.records])
+            ref_losses.append(float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index,
+                                                      sb.features)[0]))
+        hip, ref = torch.tensor(hip_losses), torch.tensor(ref_losses)
+        assert ref[-8:].mean() < 0.7 * ref[:8].mean(), "planted task should be learnable"
+        assert ((hip - ref).abs() / ref.abs()).max().item() < 1e-2, (hip_losses[-5:], ref_losses[-5:])
+        held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
+        est_hip, cand = solver.predict(held)
+        est_ref = oracle.forward(held.meg, held.positions(), held.subject_index)
+        acc_hip = retrieval.segment_topk_accuracy(ClipLoss().cuda(), est_hip, cand, topks=(1, 10))
+        probs_ref = O.clip_probabilities(est_ref, held.features)
+    finally:
+        torch.set_num_threads(prev_threads)
+        H.set_kernel_timer(None)
     labels = torch.arange(n_held)
     acc_ref = {k: O.topk_accuracy(probs_ref, labels, labels, k) for k in (1, 10)}
-    assert 0.40 <= acc_ref[10] <= 0.70, ("the planted task must stay away from saturation", acc_ref)
+    print(f"parity run: loss {ref_losses[0]:.3f} -> {ref_losses[-1]:.3f}, top-10 hip {acc_hip['top10']:.4f} "
+          f"oracle {acc_ref[10]:.4f}, top-1 hip {acc_hip['top1']:.4f} oracle {acc_ref[1]:.4f}")
+    assert 0.15 <= acc_ref[10] <= 0.85, ("the planted task must stay away from saturation", acc_ref)
     for k in (1, 10):
         assert abs(acc_hip[f"top{k}"] - acc_ref[k]) <= 0.01 + 1e-9, (k, acc_hip, acc_ref)
 

@@ -104,3 +104,47 @@ def test_scale_reject_oracle_matches_reference(tag, clip):
     assert torch.equal(meg, g.t(f"{tag}/meg"))
     assert torch.equal(feats, g.t(f"{tag}/features"))
     assert clip or int((~keep).sum()) == 2
+
+
+def test_retrieval_rules_match_the_reference_functions():
+    """tests/golden/retrieval_rules.npz was produced by EXECUTING scripts/run_eval_probs.py:237-264
+    (`_get_accuracy_from_probs`) and the per-segment loop of bm/wer.py:82-121 from the reference sources
+    (tests/golden/make_golden.py::retrieval_fixture); the oracle's restatements must reproduce them."""
+    import json
+    g = Golden("retrieval_rules")
+    probs, vocab, target = g.t("acc/probs"), g.t("acc/vocab_labels"), g.t("acc/target_labels")
+    for k in (1, 5, 10):
+        assert O.topk_accuracy(probs, vocab, target, k) == pytest.approx(float(g.raw[f"acc/top{k}"]), abs=1e-9)
+    assert 0.0 < float(g.raw["acc/top10"]) < 1.0
+    meta = json.loads(str(g.raw["wer/meta"]))
+    got = O.get_wer_loop(g.t("wer/estimates"), g.t("wer/outputs"), g.t("wer/word_hashes"), g.t("wer/kept"),
+                         topx=meta["topx"])
+    assert got["wer"] == pytest.approx(float(g.raw["wer/wer"]), abs=1e-9)
+    assert got["wer_vocab"] == pytest.approx(float(g.raw["wer/wer_vocab"]), abs=1e-9)
+    assert 0.0 < got["wer_vocab"] < got["wer"] < 1.0
+
+
+def test_mne_layout_branch_matches_the_reference(monkeypatch):
+    """`PositionGetter._layout_from_mne` -- the branch every REAL recording takes -- against positions computed by
+    the reference's `get_recording_layout` (bm/models/common.py:190-222) under a stub `mne.find_layout`
+    (tests/golden/make_golden.py::mne_layout_fixture): suffixed channel names, channels the layout lacks
+    (INVALID = -0.1), layout rows in another order than the recording's channels."""
+    import sys
+    import types
+    import numpy as np
+    from brainmagick_amd.models.common import PositionGetter
+    g = Golden("mne_layout")
+    layout = types.SimpleNamespace(names=[str(n) for n in g.raw["layout_names"]], pos=np.array(g.raw["layout_pos"]))
+    stub = types.ModuleType("mne")
+    stub.find_layout = lambda info: layout
+    monkeypatch.setitem(sys.modules, "mne", stub)
+    info = types.SimpleNamespace(ch_names=[str(n) for n in g.raw["ch_names"]])
+    rec = types.SimpleNamespace(recording_index=7, mne_info=info, layout=None)
+    getter = PositionGetter()
+    got = getter.get_recording_layout(rec)
+    want = g.t("positions")
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    assert torch.equal(got, want), (got - want).abs().max()
+    assert getter.get_recording_layout(rec) is got                       # cached per recording_index
+    assert getter._invalid_names == {"UADC001", "STIM"}
+    assert int(getter.is_invalid(got).sum()) == 2
