@@ -182,7 +182,7 @@ def retrieval_block(workload, B, steps, dev, n_train=16, n_held=4, noise=3.4):
 # Dimensions of the long-horizon parity run: like tests/test_model_gpu.py::PARITY_DIMS, chosen so that every
 # contraction runs in the kernels of the headline benchmark (wide f16x2 conv / weight gradient / score kernels).
 PARITY_DIMS = dict(C=64, T=192, F=128, S=4, B=128, hidden=256, merger_channels=256, depth=4)
-PARITY_NOISE = 1.0
+PARITY_NOISE = 2.5
 
 
 def retrieval_parity_block(dev, steps=120, noise=PARITY_NOISE):
@@ -195,7 +195,7 @@ def retrieval_parity_block(dev, steps=120, noise=PARITY_NOISE):
     from brainmagick_amd.losses import ClipLoss
     d = PARITY_DIMS
     cfg = dict(O.CLIP_CONV_CFG)
-    cfg.update(merger_pos_dim=128, merger_channels=d["merger_channels"], initial_linear=d["merger_channels"],
+    cfg.update(merger_pos_dim=288, merger_channels=d["merger_channels"], initial_linear=d["merger_channels"],
                depth=d["depth"], merger_dropout=0.0)
     C, T, Fd, S, B, hidden, n_held = d["C"], d["T"], d["F"], d["S"], d["B"], d["hidden"], 1024
     torch.manual_seed(5)

@@ -7,6 +7,7 @@ struct ConvNNArgs {
     const float* wp;                           // packed [G][nchunk][KS][BKC][Mpad]
     const int* widx;                           // [B] weight-group per segment, or null (group 0)
     const float* bias;                         // [M] or null
+    long bias_gstride;                         // 0, or the stride between the bias vectors of weight groups (widx)
     const float* ep_scale; const float* ep_shift;   // [M] per-channel affine applied before act, or null
     const float* res;     long res_bstride;    // residual added after act, or null
     float* y_pre;                              // pre-activation output (after bias), or null
@@ -22,11 +23,14 @@ struct ConvNNArgs {
 // ep[0..BM) = bias, ep[BM..2BM) = scale, ep[2BM..3BM) = shift.  Reading them from global memory per
 // element serialises hundreds of dependent L2 round trips per wavefront at the end of every tile.
 __device__ __forceinline__ void conv_ep_stage_params(const ConvNNArgs& a, float* ep, int BM, int m0, int tid,
-                                                     int nthreads) {
+                                                     int nthreads, int b) {
+    // per-group bias (the composed front end: bias = W_subject^T b_initial differs per subject)
+    const float* bias = a.bias;
+    if (bias && a.bias_gstride && a.widx) bias += (long)a.widx[b] * a.bias_gstride;
     for (int i = tid; i < BM; i += nthreads) {
         const int row = m0 + i;
         const bool ok = row < a.M;
-        ep[i] = (a.bias && ok) ? a.bias[row] : 0.f;
+        ep[i] = (bias && ok) ? bias[row] : 0.f;
         ep[BM + i] = (a.ep_scale && ok) ? a.ep_scale[row] : 1.f;
         ep[2 * BM + i] = (a.ep_shift && ok) ? a.ep_shift[row] : 0.f;
     }
@@ -107,7 +111,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvNNArgs& a, f32x16 (
     float* red = smem;
     float* ep = smem + 8 * BM;
     __syncthreads();                 // every wavefront is done with the operand tiles
-    conv_ep_stage_params(a, ep, BM, m0, tid, 256);
+    conv_ep_stage_params(a, ep, BM, m0, tid, 256, b);
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -282,7 +282,7 @@ extern "C" int bm_pack_weights_bf16(const float* src, void* dst, int G, int M, i
 // Same contract as bm_conv1d_nn, with bf16-rounded MFMA operands (weights packed by
 // bm_pack_weights_bf16); x, bias, residual, outputs are fp32.
 extern "C" int bm_conv1d_nn_bf16(const float* x, long x_bstride, const void* wpacked, const int* widx,
-                                 const float* bias, const float* ep_scale, const float* ep_shift,
+                                 const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift,
                                  const float* res, long res_bstride, float* y_pre, float* y_out,
                                  long y_bstride, float* stats, int B, int Cin, int M, int T, int KS,
                                  int dil, int act, float leak, void* stream) {
@@ -292,7 +292,7 @@ extern "C" int bm_conv1d_nn_bf16(const float* x, long x_bstride, const void* wpa
     BM_REQUIRE(B >= 0 && Cin > 0 && M > 0 && T > 0 && dil >= 1, "conv1d_nn_bf16: bad dims");
     BM_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv1d_nn_bf16: scale/shift must come together");
     ConvNNArgs a;
-    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias;
+    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias; a.bias_gstride = bias_gstride;
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
     a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = stats;
     a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;

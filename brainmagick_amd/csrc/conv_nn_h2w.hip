@@ -37,7 +37,7 @@ struct ConvH2Args {
     ConvNNArgs c;
     const float* x_amax;      // [BM_AMAX_SHARDS] shards whose maximum bounds |x| of the input tensor, device memory
     const float* wscale;      // [G][Mpad] inverse row scales written by bm_pack_weights_h2
-    float* y_amax_ws;         // [>= grid] or null: per-workgroup max |y_out| (bm_publish_amax), folded by bm_amax_finalize
+    BmAmaxDst y_amax;         // where max |y_out| goes (bm_publish_amax): the zeroed slot, or per-workgroup partials
 };
 
 // Power-of-two scale s with amax * s in [2^14, 2^15), and its exact inverse.  amax == 0 / subnormal / inf /
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     // activation, residual.  One literal-indexed expansion per accumulator block keeps the accumulators in
     // registers.  ep[3 HBM .. 4 HBM) = per-row accumulator factor = inverse weight-row scale x inverse x scale.
     float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
-    conv_ep_stage_params(a, ep, HBM, m0, tid, 256);
+    conv_ep_stage_params(a, ep, HBM, m0, tid, 256, b);
     {
         const float* ws = args.wscale + (long)g * a.Mpad + m0;
         for (int i = tid; i < HBM; i += 256) ep[3 * HBM + i] = ws[i] * sx_inv;
@@ -480,11 +480,11 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
         const int col0 = n0 + wn * (NW * 32) + nl;
         const float amx = m0 + HBM <= a.M ? h2_simple_tile<MW, true>(e, acc, col0, a.T)
                                           : h2_simple_tile<MW, false>(e, acc, col0, a.T);
-        if (a.y_out) bm_publish_amax(amx, args.y_amax_ws, smem + 4 * HBM);
+        if (a.y_out) bm_publish_amax(amx, args.y_amax, smem + 4 * HBM);
     } else {
         const float amx = h2_general_blocks<MW, 0>(a, acc, ep, b, m0, wm * (MW * 32) + 4 * h,
                                                    n0 + wn * (NW * 32) + nl, 0.f);
-        bm_publish_amax(amx, args.y_amax_ws, smem + 4 * HBM);
+        bm_publish_amax(amx, args.y_amax, smem + 4 * HBM);
     }
 #ifdef HG_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile's stores have left the CU
@@ -767,12 +767,13 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
     args.c.ntiles_m = args.c.Mpad / HBM;
     const long nblocks = (long)args.c.B * args.c.ntiles_n * args.c.ntiles_m;
     if (nblocks <= 0) return BM_OK;
-    const bool publish = y_amax_out && args.y_amax_ws && nblocks <= BM_AMAX_WS;
-    float* ws = args.y_amax_ws;
-    if (!publish) args.y_amax_ws = nullptr;
+    // two-stage mode: the workspace bounds the grid (atomic mode has no such limit)
+    const bool publish = y_amax_out && (args.y_amax.slot || (args.y_amax.ws && nblocks <= BM_AMAX_WS));
+    float* ws = args.y_amax.ws;
+    if (!publish) args.y_amax = BmAmaxDst{nullptr, nullptr};
     hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
     if (int rc = bm_check_launch("conv_nn_h2w")) return rc;
-    if (publish) return bm_amax_finalize(ws, (int)nblocks, y_amax_out, stream);
+    if (publish) return bm_amax_done(args.y_amax, (int)nblocks, y_amax_out, stream);
     if (y_amax_out && ws)           // grid larger than the workspace: a plain pass over the output instead
         return bm_amax(args.c.y_out, (long)args.c.B * args.c.M * args.c.T, y_amax_out, ws, stream);
     return BM_OK;
@@ -783,7 +784,7 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
 // contraction that consumes the output; `amax_ws` = BM_AMAX_WS floats of scratch shared by all producers of the stream); weights packed by bm_pack_weights_h2; only shapes for which
 // bm_conv_h2_covers() is 1.
 extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked,
-                               const int* widx, const float* bias, const float* ep_scale, const float* ep_shift,
+                               const int* widx, const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift,
                                const float* res, long res_bstride, float* y_pre, float* y_out, long y_bstride,
                                float* stats, int B, int Cin, int M, int T, int KS, int dil, int act, float leak,
                                int G, float* y_amax_out, float* amax_ws, void* stream) {
@@ -796,7 +797,7 @@ extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_am
                Cin, M, T, KS, dil);
     ConvH2Args args;
     ConvNNArgs& a = args.c;
-    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias;
+    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias; a.bias_gstride = bias_gstride;
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
     a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = nullptr;
     a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;
@@ -807,7 +808,7 @@ extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_am
     args.x_amax = x_amax;
     BM_REQUIRE(!y_amax_out || amax_ws, "conv1d_nn_h2: y_amax_out needs the amax workspace");
     if (!y_out) y_amax_out = nullptr;
-    args.y_amax_ws = y_amax_out ? amax_ws : nullptr;
+    args.y_amax = bm_amax_dst(y_amax_out, amax_ws);
     args.wscale = reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpacked) + f16_elems * 2);
     hipStream_t s = (hipStream_t)stream;
 #define H2_DISPATCH(MW_)                                                                 \

@@ -264,7 +264,7 @@ extern "C" int bm_pack_weights_x3(const float* src, void* dst, int G, int M, int
 
 // Same contract as bm_conv1d_nn; weights packed by bm_pack_weights_x3; fp32-accurate (see header).
 extern "C" int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpacked, const int* widx,
-                               const float* bias, const float* ep_scale, const float* ep_shift,
+                               const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift,
                                const float* res, long res_bstride, float* y_pre, float* y_out,
                                long y_bstride, float* stats, int B, int Cin, int M, int T, int KS,
                                int dil, int act, float leak, void* stream) {
@@ -274,7 +274,7 @@ extern "C" int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpack
     BM_REQUIRE(B >= 0 && Cin > 0 && M > 0 && T > 0 && dil >= 1, "conv1d_nn_x3: bad dims");
     BM_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv1d_nn_x3: scale/shift must come together");
     ConvNNArgs a;
-    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias;
+    a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias; a.bias_gstride = bias_gstride;
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
     a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = stats;
     a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;

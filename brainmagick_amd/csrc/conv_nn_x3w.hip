@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv_nn_x3w_kernel(ConvNNArgs a) {
     // epilogue: bias, optional pre-activation store, per-channel affine, activation, residual.
     // One literal-indexed expansion per accumulator block keeps the 240 accumulators in registers.
     float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
-    conv_ep_stage_params(a, ep, WBM, m0, tid, 256);
+    conv_ep_stage_params(a, ep, WBM, m0, tid, 256, b);
     __syncthreads();
     // Common case (every wide launch of the training step): one output tensor, no affine / activation, tile
     // fully inside M.  Row addresses are wave-uniform bases + one per-lane offset + an immediate per column

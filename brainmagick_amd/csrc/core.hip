@@ -1,6 +1,7 @@
 // Error convention + version of the C-ABI (include/bm_hip.h).
 #include "bm_common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 thread_local char bm_err_buf[512] = {0};
 
@@ -52,3 +53,15 @@ int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream) {
 }
 
 extern "C" int bm_amax_ws_elems(void) { return BM_AMAX_WS; }
+
+// Producers raise a pre-zeroed amax slot with atomic max (default) or store per-workgroup partial maxima that a
+// finalize launch folds (BM_AMAX_ATOMIC=0: A/B measurements, and the contract of round 2).
+int bm_amax_atomic() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("BM_AMAX_ATOMIC");
+        on = !(e && e[0] == '0');
+    }
+    return on;
+}
+extern "C" int bm_amax_is_atomic(void) { return bm_amax_atomic(); }

@@ -125,7 +125,7 @@ template <int VEC>
 __global__ void affine_act_res_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                       const float* __restrict__ shift, const float* __restrict__ res,
                                       float* __restrict__ out, long nvec, int C, int T, int act,
-                                      float leak, float* __restrict__ amax_ws) {
+                                      float leak, BmAmaxDst amax_ws) {
     __shared__ float amax_sh[4];
     const int TV = T / VEC;
     float amx = 0.f;
@@ -157,21 +157,22 @@ extern "C" int bm_affine_act_res(const float* y, const float* scale, const float
     const long n = (long)B * C * T;
     if (n == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
+    const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     int nblk = 0;
     if (T % 4 == 0) {
         const long nvec = n / 4;
         const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
         hipLaunchKernelGGL(affine_act_res_kernel<4>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
-                           out, nvec, C, T, act, leak, amax_out ? amax_ws : nullptr);
+                           out, nvec, C, T, act, leak, amax_dst);
         nblk = blocks;
     } else {
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
         hipLaunchKernelGGL(affine_act_res_kernel<1>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
-                           out, n, C, T, act, leak, amax_out ? amax_ws : nullptr);
+                           out, n, C, T, act, leak, amax_dst);
         nblk = blocks;
     }
     if (int rc = bm_check_launch("affine_act_res")) return rc;
-    return bm_amax_finalize(amax_ws, nblk, amax_out, s);
+    return bm_amax_done(amax_dst, nblk, amax_out, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ partial, int bn_train, float* __restrict__ dy,
     double* __restrict__ dy_partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-    int C, int T, int act, float leak, float* __restrict__ amax_ws) {
+    int C, int T, int act, float leak, BmAmaxDst amax_ws) {
     __shared__ double sh[4];
     __shared__ float amax_sh[4];
     float amx = 0.f;
@@ -309,6 +310,7 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     double* partial = (double*)workspace;
     double* dy_partial = partial + (long)2 * C * nsplit;
     hipStream_t s = (hipStream_t)stream;
+    const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     const dim3 grid(C, nsplit);
     const bool reduce = bn_train || (scale && (dgamma || dbeta));
     if (T % 4 == 0) {
@@ -317,20 +319,20 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
-                           amax_out ? amax_ws : nullptr);
+                           amax_dst);
     } else {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
-                           amax_out ? amax_ws : nullptr);
+                           amax_dst);
     }
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dy_partial,
                            dbias, C, nsplit);
     if (int rc = bm_check_launch("act_bn_bwd")) return rc;
-    return bm_amax_finalize(amax_ws, C * nsplit, amax_out, s);
+    return bm_amax_done(amax_dst, C * nsplit, amax_out, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,6 +379,34 @@ extern "C" int bm_channel_sum(const float* x, long bstride, float* out, void* wo
     hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, out, C,
                        nsplit);
     return bm_check_launch("channel_sum");
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[c][b] = sum_t x[b][c][t]: the per-segment time sums of a gradient, transposed so that a per-group
+// (subject / layout) segmented sum over b runs along the contiguous axis (bias term of the composed front end,
+// functional.FusedFrontEndFn).  One wavefront per (b, c) row, fixed summation order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_sums_t_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int B, int C, int T) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * C) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = x + row * T;
+    float s = 0.f;
+    for (int t = lane; t < T; t += 64) s += p[t];
+    s = bm_wave_sum(s);
+    if (lane == 0) {
+        const int b = (int)(row / C), c = (int)(row - (long)b * C);
+        out[(long)c * B + b] = s;
+    }
+}
+
+extern "C" int bm_time_sums_t(const float* x, float* out, int B, int C, int T, void* stream) {
+    BM_REQUIRE(x && out && B >= 0 && C > 0 && T > 0, "time_sums_t: bad arguments");
+    if (B == 0) return BM_OK;
+    hipLaunchKernelGGL(time_sums_t_kernel, dim3((unsigned)(((long)B * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, out, B, C, T);
+    return bm_check_launch("time_sums_t");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,7 +457,7 @@ extern "C" int bm_channel_stats(const float* x, float* stats, int B, int C, int 
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ void glu_fwd_kernel(const float* __restrict__ u, float* __restrict__ out, long nvec, int H,
-                               int T, float* __restrict__ amax_ws) {
+                               int T, BmAmaxDst amax_ws) {
     __shared__ float amax_sh[4];
     const int TV = T / VEC;
     float amx = 0.f;
@@ -456,19 +486,20 @@ extern "C" int bm_glu_fwd(const float* u, float* out, int B, int H, int T, float
     const long n = (long)B * H * T;
     if (n == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
+    const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     int nblk = 0;
     if (T % 4 == 0) {
         const long nvec = n / 4;
         const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
-        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T, amax_out ? amax_ws : nullptr);
+        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T, amax_dst);
         nblk = blocks;
     } else {
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
-        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T, amax_out ? amax_ws : nullptr);
+        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T, amax_dst);
         nblk = blocks;
     }
     if (int rc = bm_check_launch("glu_fwd")) return rc;
-    return bm_amax_finalize(amax_ws, nblk, amax_out, s);
+    return bm_amax_done(amax_dst, nblk, amax_out, s);
 }
 
 // du_a = dout * sig(g) ; du_g = dout * a * sig(g) * (1 - sig(g)); also per-channel sums (bias grad).
@@ -476,7 +507,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ dout,
                                                       const float* __restrict__ u, float* __restrict__ du,
                                                       double* __restrict__ partial, int B, int H, int T,
-                                                      float* __restrict__ amax_ws) {
+                                                      BmAmaxDst amax_ws) {
     __shared__ double sh[4 * 2];
     __shared__ float amax_sh[4];
     float amx = 0.f;
@@ -530,15 +561,16 @@ extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* d
         return bm_set_error(BM_ERR_WORKSPACE, "glu_bwd: workspace too small");
     double* partial = (double*)workspace;
     hipStream_t s = (hipStream_t)stream;
+    const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     if (T % 4 == 0)
         hipLaunchKernelGGL(glu_bwd_kernel<4>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T,
-                           amax_out ? amax_ws : nullptr);
+                           amax_dst);
     else
         hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T,
-                           amax_out ? amax_ws : nullptr);
+                           amax_dst);
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, s, partial,
                            dbias, 2 * H, nsplit);
     if (int rc = bm_check_launch("glu_bwd")) return rc;
-    return bm_amax_finalize(amax_ws, H * nsplit, amax_out, s);
+    return bm_amax_done(amax_dst, H * nsplit, amax_out, s);
 }

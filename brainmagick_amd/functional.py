@@ -247,6 +247,95 @@ class ChannelMergerFn(torch.autograd.Function):
         return dmeg, dheads, None, None, None, None
 
 
+class FusedFrontEndFn(torch.autograd.Function):
+    """ChannelMerger apply -> initial 1x1 conv -> SubjectLayers (bm/models/common.py:355-358,
+    bm/models/simpleconv.py:113-120, bm/models/common.py:55-58) as ONE grouped 1x1 conv.
+
+    In the paper's configuration nothing non-linear sits between the three maps, so for a segment of layout u and
+    subject s      y = Ws[s]^T (W1 (Wm[u] x) + b1) = Wc[u,s] x + bc[u,s],   Wc = Ws[s]^T W1 Wm[u].
+    The composed [D, C] matrices (one per (layout, subject) pair, U*S of them: 27 for one MEG system) cost
+    ~1 GFLOP per step; in exchange the two [B, 270, T] intermediates (99.5 MB each at B = 256) are never written
+    or read, two of the three forward convs, both data-gradient convs and two of the three weight-gradient
+    contractions disappear.  Backward: ONE grouped weight-gradient contraction G[u,s] = sum_{b in (u,s)} dy_b x_b^T
+    over the batch, then the chain rule through the small matrices:
+        dWs[s] = sum_u [P[u] | b1] [G | cs]^T,   A[u,s] = Ws[s] [G | cs],   dW1 = sum_u (sum_s A) Wm[u]^T,
+        db1 = sum_{u,s} A[:, C],   dWm[u] = W1^T sum_s A[u,s]   (then the softmax / logits backward of the merger)
+    with P[u] = W1 Wm[u] and cs[u,s] = sum_{b in (u,s), t} dy_b (the bias column, carried as column C of the
+    augmented matrices).  The small products run on the fp32-accurate narrow kernels in every fp32-class mode.
+    Mathematically identical to the three-layer chain; the rounding differs at the fp32 level (re-association)."""
+
+    @staticmethod
+    def forward(ctx, meg, heads, w1, b1, ws, positions_u, layout_index, subjects, ban_center, ban_radius: float):
+        meg, heads, w1, ws, positions_u = _c(meg), _c(heads), _c(w1), _c(ws), _c(positions_u)
+        U, C, _ = positions_u.shape
+        O, Dp = heads.shape
+        L = w1.shape[0]
+        S, _, D = ws.shape
+        B, _, T = meg.shape
+        dev = meg.device
+        # spatial-attention weights per layout (as ChannelMergerFn)
+        emb = H.fourier_emb(positions_u, Dp)
+        seg_u = torch.arange(U + 1, dtype=torch.int32, device=dev)
+        scores = H.gemm_nt(heads, emb, U, O, C, Dp, a_strides=(0, Dp), x_strides=(C * Dp, Dp), seg=seg_u,
+                           G=U, force_f32=True).view(U, O, C)
+        wm = H.masked_softmax(scores, positions_u, ban_center, ban_radius)              # [U, O, C]
+        # P[u] = W1 Wm[u], with b1 as column C
+        _, p, _ = H.conv_nn(wm, H.pack_conv_fwd(w1), L, 1, 1)                           # [U, L, C]
+        bcol = (b1 if b1 is not None else torch.zeros(L, device=dev)).view(1, L, 1).expand(U, L, 1)
+        xp = torch.cat([p, bcol], dim=2).repeat_interleave(S, dim=0).contiguous()       # [U*S, L, C+1], pair = u*S + s
+        widx_p = torch.arange(S, dtype=torch.int32, device=dev).repeat(U)
+        # Wc[u,s] = Ws[s]^T [P[u] | b1]
+        _, wc, _ = H.conv_nn(xp, H.pack_weights(ws, S, D, L, 1, L * D, 1, D, 0), D, 1, 1, widx=widx_p)   # [U*S, D, C+1]
+        bias_c = wc[:, :, C].contiguous()                                               # [U*S, D]
+        pair = H.index_i32(_c(layout_index.to(torch.int64)), U) * S + H.index_i32(_c(subjects.to(torch.int64)), S)
+        wpc = H.pack_weights(wc, U * S, D, C, 1, D * (C + 1), C + 1, 1, 0, shape=(T, 1))
+        _, out, _ = H.conv_nn(meg, wpc, D, 1, 1, widx=pair, bias=bias_c, bias_gstride=D)
+        ctx.save_for_backward(meg, emb, wm, xp, ws, w1, pair, widx_p, wc)
+        ctx.dims = (U, C, O, Dp, L, S, D)
+        ctx.has_b1 = b1 is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        meg, emb, wm, xp, ws, w1, pair, widx_p, wc = ctx.saved_tensors
+        U, C, O, Dp, L, S, D = ctx.dims
+        dout = _c(dout)
+        B, _, T = meg.shape
+        dev = meg.device
+        P = U * S
+        # G[p] = sum_{b in p} dy_b x_b^T and the per-pair time sums of dy as column C
+        order, seg = H.group_by_index(pair.to(torch.int64), P)
+        gaug = torch.empty(P, D, C + 1, device=dev, dtype=torch.float32)
+        H.gemm_nt(dout, meg, B, D, C, T, 1, 1, order=order, seg=seg, G=P, out=gaug,
+                  out_strides=(D * (C + 1), C + 1, 1, 0))
+        gaug[:, :, C] = H.segment_sum_cols(H.time_sums_t(dout), order, seg).t()
+        seg_p = torch.arange(P + 1, dtype=torch.int32, device=dev)
+        dws = dw1 = db1 = dheads = None
+        if ctx.needs_input_grad[4]:
+            t1 = H.gemm_nt(xp, gaug, P, L, D, C + 1, seg=seg_p, G=P)                    # [P, L, D, 1]
+            dws = (H.sum_over_batch(t1.view(U, S * L * D)) if U > 1 else t1).view(S, L, D)
+        # A[p] = Ws[s] [G | cs], summed over the subjects of a layout
+        _, a, _ = H.conv_nn(gaug, H.pack_weights(ws, S, L, D, 1, L * D, D, 1, 0), L, 1, 1, widx=widx_p)   # [P, L, C+1]
+        a_u = torch.stack([H.sum_over_batch(a[u * S:(u + 1) * S]) for u in range(U)])   # [U, L, C+1]
+        if ctx.has_b1 and ctx.needs_input_grad[3]:
+            db1 = H.sum_over_batch(a_u[:, :, C].contiguous()) if U > 1 else a_u[0, :, C].contiguous()
+        if ctx.needs_input_grad[2]:
+            dw1 = H.gemm_nt(a_u, wm, U, L, O, C, 1, 1, a_strides=(L * (C + 1), C + 1),
+                            x_strides=(O * C, C)).view(L, O, 1)
+        if ctx.needs_input_grad[1]:
+            _, dwm, _ = H.conv_nn(a_u, H.pack_conv_dgrad(w1), O, 1, 1)                  # [U, O, C+1]
+            dscores = H.softmax_bwd(wm, dwm[:, :, :C].contiguous())
+            wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0, shape=(Dp, 1))
+            uidx = torch.arange(U, dtype=torch.int32, device=dev)
+            _, per_layout, _ = H.conv_nn(emb, wp, O, 1, 1, widx=uidx)                  # [U, O, Dp]
+            dheads = H.sum_over_batch(per_layout) if U > 1 else per_layout[0]
+        dmeg = None
+        if ctx.needs_input_grad[0]:
+            wpt = H.pack_weights(wc, P, C, D, 1, D * (C + 1), 1, C + 1, 0, shape=(T, 1))
+            _, dmeg, _ = H.conv_nn(dout, wpt, C, 1, 1, widx=pair)
+        return dmeg, dheads, dw1, db1, dws, None, None, None, None, None
+
+
 # The wide kernels address one operand with 32-bit byte offsets and the conv stages a [Cin, T] window per segment:
 # a candidate set beyond 1 GB (2 048 wav2vec2-sized candidates gathered from 8 GPUs = 3 GB) is walked in row
 # blocks -- which are also the blocks the per-rank gather delivers.

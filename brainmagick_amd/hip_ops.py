@@ -166,7 +166,8 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
         return None
     pool = _amax_pool.get(t.device)
     if pool is None or pool[1] >= pool[0].numel():
-        pool = _amax_pool[t.device] = [torch.empty(4096 * AMAX_SHARDS, device=t.device, dtype=torch.float32), 0]
+        # zeroed: the producers raise their slot with atomic max (one fill per 4 096 slots)
+        pool = _amax_pool[t.device] = [torch.zeros(4096 * AMAX_SHARDS, device=t.device, dtype=torch.float32), 0]
     slot = pool[0][pool[1]:pool[1] + AMAX_SHARDS]
     pool[1] += AMAX_SHARDS
     t._bm_amax = (t._version, t.data_ptr(), slot, False)
@@ -340,10 +341,11 @@ def pack_conv_dgrad(weight: torch.Tensor, shape=None) -> torch.Tensor:
 def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: int = 1,
             widx: tp.Optional[torch.Tensor] = None, bias=None, scale=None, shift=None, res=None,
             act: int = ACT_NONE, leak: float = 0., want_pre: bool = False, want_out: bool = True,
-            want_stats: bool = False, out: tp.Optional[torch.Tensor] = None):
+            want_stats: bool = False, out: tp.Optional[torch.Tensor] = None, bias_gstride: int = 0):
     """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T].  ``out``: write y_out there instead of
     allocating (it may be ``res`` itself: every element is read and written by the same thread, which is how the
-    ClipLoss backward accumulates over candidate blocks)."""
+    ClipLoss backward accumulates over candidate blocks).  ``bias_gstride`` > 0: ``bias`` holds one vector per weight
+    group, ``bias_gstride`` floats apart, selected by ``widx`` like the weights."""
     _req(x, "conv_nn.x")
     mode = getattr(wpacked, "_bm_mode", "f32")      # set by pack_weights
     _req(wpacked, "conv_nn.w", {"f32": torch.float32, "f16x2": torch.uint8}.get(mode, torch.bfloat16))
@@ -363,7 +365,7 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))
-    common = (_p(_opt(widx, "widx", torch.int32)), _p(_opt(bias, "bias")), _p(_opt(scale, "scale")),
+    common = (_p(_opt(widx, "widx", torch.int32)), _p(_opt(bias, "bias")), bias_gstride, _p(_opt(scale, "scale")),
               _p(_opt(shift, "shift")), _p(res), M * T, _p(y_pre), _p(y_out), M * T, _p(stats), B, Cin, M, T,
               KS, dil, act, leak)
     if mode == "f16x2":
@@ -635,6 +637,15 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
     stats = torch.empty(lib().bm_channel_stats_splits(B), C, 2, device=x.device, dtype=torch.float32)
     check(lib().bm_channel_stats(_p(x), _p(stats), B, C, T, _stream()), "bm_channel_stats")
     return stats
+
+
+def time_sums_t(x: torch.Tensor) -> torch.Tensor:
+    """[B, C, T] -> [C, B]: out[c][b] = sum_t x[b][c][t]."""
+    _req(x, "time_sums_t.x")
+    B, C, T = x.shape
+    out = torch.empty(C, B, device=x.device, dtype=torch.float32)
+    check(lib().bm_time_sums_t(_p(x), _p(out), B, C, T, _stream()), "bm_time_sums_t")
+    return out
 
 
 def glu_fwd(u: torch.Tensor) -> torch.Tensor:

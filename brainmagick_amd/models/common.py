@@ -322,7 +322,9 @@ class ChannelMerger(nn.Module):
     def training_penalty(self):
         return self._penalty.to(next(self.parameters()).device)
 
-    def forward(self, meg, batch):
+    def layouts_and_ban(self, meg, batch):
+        """(positions_u [U, C, 2], layout_index [B], ban_center | None, radius): the layout-dependent inputs of the
+        attention, shared by ``forward`` and by SimpleConv's composed front end."""
         B, C, T = meg.shape
         positions_u, layout_index = self.position_getter.get_unique_layouts(batch, C, meg.device)
         ban_center, radius = None, 0.
@@ -332,6 +334,10 @@ class ChannelMerger(nn.Module):
             else:
                 ban_center = torch.rand(2, device=meg.device)        # common.py:343
             radius = float(self.dropout)
+        return positions_u, layout_index, ban_center, radius
+
+    def forward(self, meg, batch):
+        positions_u, layout_index, ban_center, radius = self.layouts_and_ban(meg, batch)
         return BF.ChannelMergerFn.apply(meg, self.heads, positions_u, layout_index, ban_center,
                                         radius)
 

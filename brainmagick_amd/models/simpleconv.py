@@ -17,6 +17,11 @@ from .common import (
 from .. import functional as BF
 from .. import hip_ops as H
 
+import os
+
+# A/B switch (measurement / tests): "0" keeps the three front-end layers as three kernels even where they compose
+_FUSE_FRONT_END = os.environ.get("BM_FUSE_FRONT_END", "1") == "1"
+
 
 class SimpleConv(nn.Module):
     """Constructor keywords, defaults, sub-module names and ``state_dict`` keys are the reference's
@@ -125,6 +130,12 @@ class SimpleConv(nn.Module):
             width += subject["emb_dim"]
         return width
 
+    def _front_end_is_linear_chain(self) -> bool:
+        """merger -> ONE 1x1 conv (no activation) -> subject layers: the paper's front end
+        (conf/model/clip_conv.yaml: initial_depth 1, no initial_nonlin), composable into one grouped 1x1 conv."""
+        return (self.merger is not None and self.subject_layers is not None and self.initial_linear is not None
+                and len(self.initial_linear) == 1 and self.subsampled_meg_channels is None)
+
     def forward(self, inputs, batch):
         subjects = batch.subject_index
         length = inputs["meg"].shape[-1]
@@ -137,9 +148,24 @@ class SimpleConv(nn.Module):
 
         if self.subsampled_meg_channels is not None:
             x = x * self._channel_keep                       # constant 0/1 mask, simpleconv.py:202-205
-        if self.merger is not None:
+        fused = self._front_end_is_linear_chain() and _FUSE_FRONT_END
+        if fused:
+            positions_u, layout_index, ban_center, radius = self.merger.layouts_and_ban(x, batch)
+            # one composed matrix per (layout, subject) pair: worth it while there are fewer pairs than segments
+            fused = positions_u.shape[0] * self.subject_layers.weights.shape[0] <= x.shape[0]
+        self.front_end_fused = fused              # introspection (tests, bench)
+        if fused:
+            conv = self.initial_linear[0]
+            x = BF.FusedFrontEndFn.apply(x, self.merger.heads, conv.weight, conv.bias, self.subject_layers.weights,
+                                         positions_u, layout_index, subjects, ban_center, radius)
+        elif self.merger is not None and self._front_end_is_linear_chain() and _FUSE_FRONT_END:
+            # the layouts (and the random ban centre) were drawn above: do not draw them twice
+            x = BF.ChannelMergerFn.apply(x, self.merger.heads, positions_u, layout_index, ban_center, radius)
+        elif self.merger is not None:
             x = self.merger(x, batch)
-        if self.initial_linear is not None:
+        if fused:
+            pass
+        elif self.initial_linear is not None:
             mods = list(self.initial_linear)
             i = 0
             while i < len(mods):
@@ -150,7 +176,7 @@ class SimpleConv(nn.Module):
                                       act.code if act is not None else H.ACT_NONE,
                                       act.leak if act is not None else 0., False)
                 i += 2 if act is not None else 1
-        if self.subject_layers is not None:
+        if self.subject_layers is not None and not fused:
             x = self.subject_layers(x, subjects)
         if self.subject_embedding is not None:
             emb = self.subject_embedding(subjects)[:, :, None]

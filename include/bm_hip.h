@@ -57,7 +57,7 @@ int bm_sum_over_batch(const float* x, float* out, int B, long n, void* stream);
  * and ClipLoss' dEstimate (losses.py:94 backward).  y_pre = value after bias; y_out = after
  * [affine ->] act [-> + res]; stats = per-tile (sum, sumsq) of y_pre for BatchNorm1d (common.py:119). */
 int bm_conv1d_nn(const float* x, long x_bstride, const float* wpacked, const int* widx,
-                 const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                 const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
                  long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                  int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
 
@@ -70,7 +70,7 @@ long bm_packed_weight_elems_bf16(int G, int M, int Cin, int KS);
 int bm_pack_weights_bf16(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
                          long sc, long sj, int flip, const float* alpha_ptr, void* stream);
 int bm_conv1d_nn_bf16(const float* x, long x_bstride, const void* wpacked, const int* widx,
-                      const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                      const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
                       long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                       int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
 
@@ -81,7 +81,7 @@ long bm_packed_weight_elems_x3(int G, int M, int Cin, int KS);
 int bm_pack_weights_x3(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
                        long sc, long sj, int flip, const float* alpha_ptr, void* stream);
 int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpacked, const int* widx,
-                    const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                    const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                     int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
 /* 1 when bm_conv1d_nn_x3 takes the wide-tile kernel (conv_nn_x3w.hip: 320 x 192 workgroup tile, one
@@ -120,14 +120,18 @@ int bm_pack_h2_job_fill(void* job, const float* src, void* dst, int G, int M, in
                         long sc, long sj, int flip, const float* alpha_ptr, int block0);
 int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, int max_nk, void* stream);
 /* amax slots and workspace: a slot is 8 floats whose maximum is max|x|; `amax_ws` is 16384 floats of scratch that
- * the producers of one stream may share (per-workgroup partial maxima, folded by a one-workgroup kernel). */
+ * the producers of one stream may share.  bm_amax / bm_amax_checked overwrite the slot (per-workgroup partial maxima
+ * in `amax_ws`, folded by a one-workgroup kernel).  The PRODUCERS (`amax_out` / `y_amax_out` arguments below) raise
+ * the slot with atomic max: the caller hands them a ZEROED slot (bm_amax_is_atomic() == 1, the default; with
+ * BM_AMAX_ATOMIC=0 in the environment they use the two-stage form as well and overwrite). */
 int bm_amax_ws_elems(void);
+int bm_amax_is_atomic(void);
 int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
 /* Same pass, plus the reference's finiteness assert (bm/solver.py:258-260): *nonfinite_flag (device int, nullable)
  * is set to 1 when x holds an inf or a nan. */
 int bm_amax_checked(const float* x, long n, float* out, float* amax_ws, int* nonfinite_flag, void* stream);
 int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked, const int* widx,
-                    const float* bias, const float* ep_scale, const float* ep_shift, const float* res,
+                    const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B, int Cin,
                     int M, int T, int KS, int dil, int act, float leak, int G, float* y_amax_out, float* amax_ws,
                     void* stream);
@@ -180,6 +184,9 @@ int bm_glu_fwd(const float* u, float* out, int B, int H, int T, float* amax_out,
 long bm_glu_bwd_workspace_bytes(int B, int H);
 int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
                long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws, void* stream);
+/* out[c][b] = sum_t x[b][c][t]  (per-segment time sums, transposed; bias gradient of the composed front end:
+ * bm/models/simpleconv.py:113-120 + bm/models/common.py:55-58 chained) */
+int bm_time_sums_t(const float* x, float* out, int B, int C, int T, void* stream);
 
 /* ---- ScaleReject front end (scale.hip)  bm/norm.py:86-87,255-261,325-341; bm/solver.py:245-246 ----
  * out = clamp((x - center[group[b]][c]) / scale[group[b]][c]); maxabs[b] = max|out[b]| (zero-init). */

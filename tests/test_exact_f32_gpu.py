@@ -97,4 +97,5 @@ def test_paper_model_step_x3(x3_mode, cfg_name, B, T):
 
 
 def test_training_curve_x3(x3_mode):
-    TM.test_training_curve_and_top10_parity()
+    # the 200-step run is the default (f16x2) mode's; the cross-check modes follow the oracle for 40 steps
+    TM.test_training_curve_and_top10_parity(steps=40, n_held=512)

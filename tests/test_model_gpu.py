@@ -19,7 +19,7 @@ LOSS_TOL = 1e-4
 
 
 NOISE = 1e-6
-PARITY_NOISE = 3.0      # planted-noise level of the long-horizon parity run (calibrated: top-10 far from 0 % and 100 %)
+PARITY_NOISE = 2.5      # planted-noise level of the long-horizon parity run (calibrated: top-10 far from 0 % and 100 %)
 
 
 def close(a, b, tol, ref_scale):
@@ -524,7 +524,7 @@ def test_two_replicas_match_the_data_parallel_oracle(negatives):
     from brainmagick_amd.solver import Solver
     world, B, steps = 2, 8, 2
     cfg = dict(O.CLIP_CONV_CFG)
-    cfg.update(merger_pos_dim=64, merger_channels=96, initial_linear=96, depth=4, merger_dropout=0.0)
+    cfg.update(merger_pos_dim=128, merger_channels=96, initial_linear=96, depth=4, merger_dropout=0.0)
     C, T, Fd, S, hidden = 30, 160, 12, 4, 96
 
     def build():
@@ -618,29 +618,29 @@ PARITY_DIMS = dict(C=64, T=192, F=128, S=4, B=128, hidden=256, merger_channels=2
 def parity_model_cfg():
     cfg = dict(O.CLIP_CONV_CFG)
     d = PARITY_DIMS
-    cfg.update(merger_pos_dim=128, merger_channels=d["merger_channels"], initial_linear=d["merger_channels"],
+    # merger_pos_dim 288 = 2 * 12^2: the attention backward contracts over the embedding axis (a "time" axis > 128)
+    cfg.update(merger_pos_dim=288, merger_channels=d["merger_channels"], initial_linear=d["merger_channels"],
                depth=d["depth"], merger_dropout=0.0)
     return cfg
 
 
-def assert_headline_kernels(names):
-    """`names`: labels of every MFMA launch of one training step (hip_ops.KernelTimer).  All convs, the dense weight
-    gradients and the score contraction must be the wide f16x2 kernels; the 3 x bf16 family may only appear for
-    the shapes it also serves in the headline run."""
-    convs = [n for n in names if n.startswith("conv_nn")]
-    assert convs and all(n.startswith("conv_nn_h2w_kernel") for n in convs), sorted(set(convs))
+def assert_headline_kernels(records):
+    """`records`: (label, flops) of every MFMA launch of one training step (hip_ops.KernelTimer).  Every launch that
+    carries real work (>= 1 GFLOP: all convs of the stack and the head, their weight gradients, the score
+    contraction and its backward) must be a wide f16x2 kernel; the 3 x bf16 family may only serve the small
+    products (per-layout attention logits, the composed front end's matrix products, the grouped per-(layout,
+    subject) weight gradient) -- as in the headline run."""
+    names = [n for n, _ in records]
+    big = [(n, f) for n, f in records if f >= 1e9]
+    assert len(big) >= 3 * (PARITY_DIMS["depth"] + PARITY_DIMS["depth"] // 2) + 4, big
+    assert all(n.startswith(("conv_nn_h2w_kernel", "gemm_nt_h2w_kernel", "clip_scores:gemm_nt_h2w")) for n, _ in big), \
+        sorted({n for n, _ in big})
     assert "clip_scores:gemm_nt_h2w" in names, sorted(set(names))
-    wide_wgrads = [n for n in names if n.startswith("gemm_nt_h2w_kernel")]
-    narrow = [n for n in names if n.startswith("gemm_nt_x3_kernel")]
-    d = PARITY_DIMS
-    n_dense = d["depth"] + d["depth"] // 2 + 2        # k3 convs + GLU convs + initial linear + head 1x1
-    assert len(wide_wgrads) >= n_dense, (len(wide_wgrads), n_dense, sorted(set(names)))
-    # merger logits, merger d(weights), subject layers, final 1x1 (M = F): the same four as at full size
-    assert len(narrow) <= 4, narrow
-    assert not [n for n in names if "_x3w" in n or n.startswith("gemm_nt_kernel") or "bf16" in n], names
+    assert not [n for n in names if "_x3w" in n or n.startswith(("gemm_nt_kernel", "conv_nn_kernel")) or "bf16" in n], \
+        sorted(set(names))
 
 
-def test_training_curve_and_top10_parity():
+def test_training_curve_and_top10_parity(steps: int = 200, n_held: int = 2048):
     """SURVEY.md §8d accuracy parity THROUGH THE HEADLINE KERNELS: train the same initial state for 200 steps on the
     same learnable (planted-latent) batches with the HIP path and with the oracle; the loss curves must agree
     within 1 % (relative, every step) and the top-10 / top-1 segment-retrieval accuracy on 2 048 held-out segments
@@ -651,35 +651,36 @@ def test_training_curve_and_top10_parity():
     from brainmagick_amd.solver import Solver
     from brainmagick_amd.losses import ClipLoss
     from brainmagick_amd import retrieval
-    assert H.get_compute_dtype() == "f16x2"
+    headline_mode = H.get_compute_dtype() == "f16x2"     # (tests/test_exact_f32_gpu.py re-runs this in the other modes)
     cfg = parity_model_cfg()
     d = PARITY_DIMS
     C, T, Fd, S, B, hidden = d["C"], d["T"], d["F"], d["S"], d["B"], d["hidden"]
-    steps, n_batches, n_held, noise = 200, 16, 2048, PARITY_NOISE
+    noise = PARITY_NOISE
     torch.manual_seed(5)
     model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden},
                        n_subjects=S, **cfg)
     oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, hidden, Fd)
     solver = Solver(model)
-    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=100 + i, planted=True, noise=noise)
-               for i in range(n_batches)]
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(min(32, prev_threads))       # the GPU box's 256 hardware threads slow torch's CPU pool down
     hip_losses, ref_losses = [], []
     try:
         for step in range(steps):
-            sb = batches[step % len(batches)]
+            # a fresh batch every step: the 2 M-parameter model would memorise a recycled set within 200 steps
+            sb = synthetic.make_batch(B, C, T, Fd, S, seed=100 + step, planted=True, noise=noise)
             if step in (0, steps - 1):                     # which kernels ran, first and last step
                 timer = H.KernelTimer()
                 H.set_kernel_timer(timer)
             hip_losses.append(float(solver.train_step(sb)))
             if step in (0, steps - 1):
                 H.set_kernel_timer(None)
-                assert_headline_kernels([r[0] for r in timer.records])
+                if headline_mode:
+                    assert_headline_kernels([(r[0], r[1]) for r in timer.records])
             ref_losses.append(float(oracle.train_step(sb.meg, sb.positions(), sb.subject_index,
                                                       sb.features)[0]))
         hip, ref = torch.tensor(hip_losses), torch.tensor(ref_losses)
-        assert ref[-8:].mean() < 0.7 * ref[:8].mean(), "planted task should be learnable"
+        if steps >= 200:
+            assert ref[-8:].mean() < 0.8 * ref[:8].mean(), "planted task should be learnable"
         assert ((hip - ref).abs() / ref.abs()).max().item() < 1e-2, (hip_losses[-5:], ref_losses[-5:])
         held = synthetic.make_batch(n_held, C, T, Fd, S, seed=999, planted=True, noise=noise)
         est_hip, cand = solver.predict(held)
@@ -693,7 +694,8 @@ def test_training_curve_and_top10_parity():
     acc_ref = {k: O.topk_accuracy(probs_ref, labels, labels, k) for k in (1, 10)}
     print(f"parity run: loss {ref_losses[0]:.3f} -> {ref_losses[-1]:.3f}, top-10 hip {acc_hip['top10']:.4f} "
           f"oracle {acc_ref[10]:.4f}, top-1 hip {acc_hip['top1']:.4f} oracle {acc_ref[1]:.4f}")
-    assert 0.15 <= acc_ref[10] <= 0.85, ("the planted task must stay away from saturation", acc_ref)
+    if steps >= 200:
+        assert 0.15 <= acc_ref[10] <= 0.9, ("the planted task must stay away from saturation", acc_ref)
     for k in (1, 10):
         assert abs(acc_hip[f"top{k}"] - acc_ref[k]) <= 0.01 + 1e-9, (k, acc_hip, acc_ref)
 
@@ -745,6 +747,52 @@ def _small_model(C=20, Fd=10, S=3, hidden=32, seed=3, **over):
     torch.manual_seed(seed)
     return SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S,
                       **cfg), cfg
+
+
+@pytest.mark.parametrize("T,widths", [(48, dict()), (200, dict(hidden=96, merger_channels=96, initial_linear=96))])
+def test_composed_front_end_matches_the_three_layer_chain(T, widths):
+    """merger -> initial 1x1 -> subject layers composed into one grouped conv per (layout, subject) pair
+    (functional.FusedFrontEndFn) against (a) the same model run layer by layer and (b) the CPU oracle: output, loss,
+    every gradient.  Two layouts, three subjects, a (layout, subject) pair that no segment carries, a sensor ban."""
+    from brainmagick_amd.models import simpleconv as SC
+    from brainmagick_amd.losses import ClipLoss
+    widths = dict(widths)
+    hidden = widths.pop("hidden", 32)
+    model, cfg = _small_model(S=3, hidden=hidden, merger_dropout=0.3, **widths)
+    B, C, Fd = 12, 20, 10
+    sb = synthetic.make_batch(B, C, T, Fd, 3, seed=4, n_layouts=2)
+    sb.subject_index[sb.recording_index == 1] = 0          # layout 1 only ever meets subject 0: empty pairs
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), cfg, hidden, Fd)
+    ban = torch.tensor([0.35, 0.55])
+    loss_ref, est_ref, grads_ref = oracle.loss_and_grads(sb.meg, sb.positions(), sb.subject_index, sb.features,
+                                                         True, ban)
+    model = model.cuda().train()
+    model.merger.ban_center_override = ban
+    sbg = sb.to("cuda")
+    mask = torch.ones(B, 1, T, dtype=torch.bool, device="cuda")
+    results = {}
+    for fuse in (True, False):
+        SC._FUSE_FRONT_END = fuse
+        try:
+            model.zero_grad(set_to_none=True)
+            est = model({"meg": sbg.meg.clone()}, sbg)
+            assert model.front_end_fused == fuse
+            loss = ClipLoss().cuda()(est, sbg.features, mask)
+            loss.backward()
+        finally:
+            SC._FUSE_FRONT_END = True
+        results[fuse] = (est.detach(), float(loss), {k: p.grad.clone() for k, p in model.named_parameters()})
+    gscale = max(v.double().norm().item() for v in grads_ref.values())
+    for fuse, (est, loss, grads) in results.items():
+        assert rel_l2(est, est_ref) < FWD_TOL, (fuse, rel_l2(est, est_ref))
+        assert abs(loss - float(loss_ref)) < LOSS_TOL
+        for k, g in grads.items():
+            assert close(g, grads_ref[k], GRAD_TOL, gscale), (fuse, k, rel_l2(g, grads_ref[k]))
+    front = [k for k in results[True][2] if k.startswith(("merger.", "initial_linear.", "subject_layers."))]
+    assert len(front) == 4, front
+    for k in front:       # the two formulations of the same gradient agree far inside the tolerance to the oracle
+        a, b = results[True][2][k], results[False][2][k]
+        assert close(a, b, 2e-5, gscale), (k, rel_l2(a, b))
 
 
 @pytest.mark.parametrize("B,T", [(1, 360), (2, 24), (3, 7), (5, 129)])
