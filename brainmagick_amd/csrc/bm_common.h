@@ -81,17 +81,18 @@ __device__ __forceinline__ double bm_wave_sum_d(double v) {
 #define BM_AMAX_WS 16384
 __device__ __forceinline__ float bm_wave_max(float v);
 // Where a producer publishes max |output|:
-//   slot != null ("atomic" mode, default): the BM_AMAX_SHARDS-float amax slot itself, ZEROED by the caller; the
+//   slot != null ("atomic" mode, BM_AMAX_ATOMIC=1): the BM_AMAX_SHARDS-float amax slot itself, ZEROED by the caller; the
 //     workgroup raises shard (workgroup id & 7) with one non-returning atomic max on the bit pattern (values are
 //     >= 0, so unsigned order = float order) -- and only if its maximum exceeds what the shard already holds, which
 //     after the first few workgroups is rare.  Order independent, hence deterministic; no follow-up launch.
-//   ws != null ("two-stage" mode, BM_AMAX_ATOMIC=0 and the stand-alone bm_amax pass): ws[workgroup id] = maximum,
+//   ws != null ("two-stage" mode, the default, and the stand-alone bm_amax pass): ws[workgroup id] = maximum,
 //     folded into the slot by the one-workgroup bm_amax_finalize launch.
 struct BmAmaxDst {
     float* ws;
     float* slot;
 };
-__device__ __forceinline__ void bm_publish_amax(float m, const BmAmaxDst& dst, float* sh /* >= blockDim / 64 floats of LDS */) {
+__device__ __forceinline__ void bm_publish_amax_at(float m, const BmAmaxDst& dst, float* sh /* >= blockDim / 64 floats of LDS */,
+                                                   unsigned wg /* index of the partial: workgroup or tile id */) {
     if (!dst.ws && !dst.slot) return;                  // kernel argument: uniform
     m = bm_wave_max(m);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
@@ -100,7 +101,6 @@ __device__ __forceinline__ void bm_publish_amax(float m, const BmAmaxDst& dst, f
         const int nw = (blockDim.x + 63) >> 6;
         float v = sh[0];
         for (int w = 1; w < nw; ++w) v = fmaxf(v, sh[w]);
-        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
         if (dst.slot) {
             unsigned* p = reinterpret_cast<unsigned*>(dst.slot) + (wg & (BM_AMAX_SHARDS - 1));
             const unsigned bits = __float_as_uint(v);
@@ -110,6 +110,9 @@ __device__ __forceinline__ void bm_publish_amax(float m, const BmAmaxDst& dst, f
             dst.ws[wg] = v;
         }
     }
+}
+__device__ __forceinline__ void bm_publish_amax(float m, const BmAmaxDst& dst, float* sh) {
+    bm_publish_amax_at(m, dst, sh, blockIdx.y * gridDim.x + blockIdx.x);
 }
 // plain-pointer form: two-stage mode into `ws`
 __device__ __forceinline__ void bm_publish_amax(float m, float* ws, float* sh) {
@@ -124,7 +127,7 @@ __device__ __forceinline__ float bm_amax_load(const float* slot) {
 // host: reduce n partial maxima (ws) into the slot `out`; no-op when out is null
 int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream);
 // host: destination of a producer's maximum for the current mode, and what follows its launch
-int bm_amax_atomic();                                   // 1 unless BM_AMAX_ATOMIC=0
+int bm_amax_atomic();                                   // 1 only with BM_AMAX_ATOMIC=1 (measured slower, core.hip)
 static inline BmAmaxDst bm_amax_dst(float* amax_out, float* amax_ws) {
     if (!amax_out) return BmAmaxDst{nullptr, nullptr};
     return bm_amax_atomic() ? BmAmaxDst{nullptr, amax_out} : BmAmaxDst{amax_ws, nullptr};

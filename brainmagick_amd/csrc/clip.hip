@@ -38,6 +38,68 @@ extern "C" int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_n
     return bm_check_launch("clip_inv_norms");
 }
 
+// The candidates' three per-step reductions in ONE pass over them (they are inputs: 44 MB at F = 120, 377 MB at
+// F = 1024 per 256 segments): inv_norm[o] (losses.py:91), max |cand| for the f16x2 scale of the score contraction
+// (raised into the ZEROED amax slot with atomic max) and the reference's finiteness assert (bm/solver.py:258-260).
+__global__ __launch_bounds__(256) void cand_prep_kernel(const float* __restrict__ cand, long K,
+                                                        float* __restrict__ inv_norm, float* __restrict__ amax_slot,
+                                                        int* __restrict__ nonfinite) {
+    __shared__ double sh[4];
+    __shared__ float shm[4];
+    const float* row = cand + (long)blockIdx.x * K;
+    double s = 0;
+    float mx = 0.f;
+    unsigned top = 0u;
+    if ((K & 3) == 0 && (((uintptr_t)row & 15) == 0)) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (long i = threadIdx.x; i < K / 4; i += blockDim.x) {
+            const float4 v = reinterpret_cast<const float4*>(row)[i];
+            a0 += v.x * v.x; a1 += v.y * v.y; a2 += v.z * v.z; a3 += v.w * v.w;
+            mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+            top = max(max(top, __float_as_uint(v.x) & 0x7fffffffu),
+                      max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu,
+                                                                   __float_as_uint(v.w) & 0x7fffffffu)));
+        }
+        s = (double)a0 + (double)a1 + (double)a2 + (double)a3;
+    } else {
+        float a = 0.f;
+        for (long i = threadIdx.x; i < K; i += blockDim.x) {
+            const float v = row[i];
+            a += v * v;
+            mx = fmaxf(mx, fabsf(v));
+            top = max(top, __float_as_uint(v) & 0x7fffffffu);
+        }
+        s = a;
+    }
+    if (nonfinite && top >= 0x7f800000u) atomicOr(nonfinite, 1);
+    s = bm_wave_sum_d(s);
+    mx = bm_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; shm[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = sh[0] + sh[1] + sh[2] + sh[3];
+        inv_norm[blockIdx.x] = 1.0f / (1e-8f + (float)sqrt(t));
+        if (amax_slot) {
+            const float m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+            unsigned* p = reinterpret_cast<unsigned*>(amax_slot) + (blockIdx.x & (BM_AMAX_SHARDS - 1));
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                (void)__hip_atomic_fetch_max(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// inv_norm as bm_clip_inv_norms (same summation order: bit-identical); amax_slot (nullable): ZEROED amax slot
+// that receives max |cand|; nonfinite_flag (nullable): set to 1 when cand holds an inf or a nan.
+extern "C" int bm_clip_cand_prep(const float* cand, int Bc, long K, float* inv_norm, float* amax_slot,
+                                 int* nonfinite_flag, void* stream) {
+    BM_REQUIRE(cand && inv_norm, "clip_cand_prep: null pointer");
+    if (Bc == 0) return BM_OK;
+    hipLaunchKernelGGL(cand_prep_kernel, dim3(Bc), dim3(256), 0, (hipStream_t)stream, cand, K, inv_norm, amax_slot,
+                       nonfinite_flag);
+    return bm_check_launch("clip_cand_prep");
+}
+
 // One workgroup (4 wavefronts) per estimate row b:
 //   scores[b][o] = inv_norm[o] * sum_split part[split][b][o]      (fixed split order: deterministic)
 //   loss_row[b]  = logsumexp_o(scores[b]) - scores[b][tgt], tgt = b + target_offset

@@ -700,12 +700,32 @@ def softmax_bwd(w, dw) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
-def clip_inv_norms(cand: torch.Tensor) -> torch.Tensor:
+def clip_inv_norms(cand: torch.Tensor, nonfinite_flag: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1 / (1e-8 + ||cand[o]||) per candidate (bm/losses.py:91).  ONE pass over the candidates also yields what else
+    a step needs from them: max |cand| (attached to the tensor like ``amax`` would, f16x2 mode) and -- with
+    ``nonfinite_flag`` -- the reference's finiteness assert.  Cached on the tensor object together with its version
+    counter: the Solver runs it when the batch arrives, ClipLoss finds the result."""
+    cached = getattr(cand, "_bm_inv_norms", None)
+    if cached is not None and cached[0] == cand._version and cached[1] == cand.data_ptr() and \
+            (nonfinite_flag is None or cached[3]):
+        return cached[2]
     _req(cand, "clip_inv_norms.cand")
     Bc = cand.shape[0]
     K = cand.numel() // max(Bc, 1)
     out = torch.empty(Bc, device=cand.device, dtype=torch.float32)
-    check(lib().bm_clip_inv_norms(_p(cand), Bc, K, _p(out), _stream()), "bm_clip_inv_norms")
+    have = getattr(cand, "_bm_amax", None)
+    have = have is not None and have[0] == cand._version and have[1] == cand.data_ptr() and \
+        (nonfinite_flag is None or have[3])
+    slot = None if have else _amax_slot(cand)            # None outside f16x2 mode
+    check(lib().bm_clip_cand_prep(_p(cand), Bc, K, _p(out), _p(slot),
+                                  _p(_opt(nonfinite_flag, "nonfinite_flag", torch.int32)), _stream()),
+          "bm_clip_cand_prep")
+    if slot is not None:
+        cand._bm_amax = (cand._version, cand.data_ptr(), slot, nonfinite_flag is not None)
+    try:
+        cand._bm_inv_norms = (cand._version, cand.data_ptr(), out, nonfinite_flag is not None)
+    except Exception:
+        pass
     return out
 
 

@@ -73,27 +73,17 @@ class Solver:
         if len(meg) == 0:
             return None
         if self.check_finite:
-            # bm/solver.py:258-260 (three separate asserts / syncs in the reference, one here); the same
-            # synchronisation point reports an out-of-range subject / layout index of the PREVIOUS step
-            # (the reference's `weights.gather` would have raised, bm/models/common.py:57)
+            # bm/solver.py:258-260 (three separate asserts / syncs in the reference, one here, in _check_flags).
             # The finiteness test rides on the max|x| pass that the f16x2 contractions need anyway (the maxima stay
             # attached to the tensors); in the other compute modes it is the one pass over each tensor.
             flag = H.index_error_flag(meg.device)
             if meg.is_contiguous() and features.is_contiguous() and meg.dtype == features.dtype == torch.float32:
                 H.amax(meg, nonfinite_flag=flag[1:2])
-                H.amax(features, nonfinite_flag=flag[1:2])
-                index_err, nonfinite, bad_mask = flag.tolist()                            # ONE sync
+                # candidates: norms, maximum and finiteness in one pass (ClipLoss finds them on the tensor)
+                H.clip_inv_norms(features, nonfinite_flag=flag[1:2])
             else:
                 finite = torch.isfinite(meg).all() & torch.isfinite(features).all()
-                index_err, nonfinite, bad_mask = torch.stack([flag[0], 1 - finite.to(torch.int32), flag[2]]).tolist()
-            if nonfinite:
-                flag[1:2].zero_()
-                raise AssertionError("non-finite values in the MEG or feature tensors")
-            if bad_mask:
-                flag[2:3].zero_()
-                raise AssertionError("mask is not supported for now (bm/losses.py:110; reported one step late)")
-            if index_err:
-                H.raise_if_index_error(meg.device)
+                flag[1:2].bitwise_or_((~finite).to(torch.int32).view(1))
         if self.offset_meg_ms:
             # bm/solver.py:262-274: brain responses lag the audio by ~150 ms
             offset = int(self.offset_meg_ms / 1000 * self.sample_rate)
@@ -107,15 +97,35 @@ class Solver:
         return batch, meg.contiguous(), features, features_mask, reject_mask
 
     def prefetch(self, next_batch) -> None:
-        """Optional: hand over the batch of the NEXT step right after a ``train_step``.  Its preparation (device
-        copy, scaling, asserts) runs now and -- the point -- with whole-node negatives its candidate all-gather
-        (3 GB at 8 x 256 wav2vec2-sized candidates, ~10 ms on xGMI against a ~5 ms forward) is enqueued on the side
-        stream behind this step's backward instead of in front of the next forward.  The next ``train_step`` /
-        ``_process_batch`` recognises the batch by identity.  Every rank must prefetch (or not) alike."""
+        """Optional: hand over the batch of the NEXT step (``train_step(batch, next_batch=...)`` calls this between
+        the loss and the backward pass).  Its preparation (device copy, scaling, the max|x| / finiteness pass) is
+        enqueued now and -- the point -- with whole-node negatives its candidate all-gather (3 GB at 8 x 256
+        wav2vec2-sized candidates, ~10 ms on xGMI against a ~5 ms forward) runs on the side stream NEXT TO THIS STEP'S
+        BACKWARD instead of in front of the next forward.  Nothing here synchronises the host (the asserts of the
+        prepared batch are read when it is consumed).  The next ``train_step`` / ``_process_batch`` recognises the
+        batch by identity.  Every rank must prefetch (or not) alike."""
         if next_batch is None:
             self._prefetched = None
             return
         self._prefetched = (next_batch, self._prepare(next_batch))
+
+    def _check_flags(self):
+        """The ONE host synchronisation of a step: the device-side flag word holds "non-finite input"
+        (bm/solver.py:258-260), "ClipLoss mask not all-true" (bm/losses.py:110) and "subject / layout index out of
+        range" (the reference's `weights.gather` would have raised, bm/models/common.py:57) -- the last two raised by
+        the PREVIOUS step."""
+        if not self.check_finite:
+            return
+        flag = H.index_error_flag(self.device)
+        index_err, nonfinite, bad_mask = flag.tolist()
+        if nonfinite:
+            flag[1:2].zero_()
+            raise AssertionError("non-finite values in the MEG or feature tensors")
+        if bad_mask:
+            flag[2:3].zero_()
+            raise AssertionError("mask is not supported for now (bm/losses.py:110; reported one step late)")
+        if index_err:
+            H.raise_if_index_error(self.device)
 
     def _process_batch(self, batch, training: bool = False):
         pre = self._prefetched
@@ -128,6 +138,7 @@ class Solver:
             prepared = self._prepare(batch)
         if prepared is None:
             return None, None, None, None
+        self._check_flags()
         batch, meg, features, features_mask, reject_mask = prepared
         inputs = dict(meg=meg)
         estimate = self.model(inputs, batch)
@@ -164,14 +175,14 @@ class Solver:
             self._last_batch = batch
         output, target_offset = self._candidates(output)
         loss = self.loss(estimate, output, features_mask, target_offset=target_offset)
+        if next_batch is not None:
+            self.prefetch(next_batch)       # the next step's candidate all-gather runs next to this backward
         # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path
         # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.collect_grads()      # one multi-tensor copy instead of an accumulate-add per parameter
         distrib.sharded_step(self.optimizer, self._buffers)
-        if next_batch is not None:
-            self.prefetch(next_batch)
         return loss.detach()
 
     # -- checkpoint (bm/solver.py:64,115-117: flashy's commit writes the registered state on rank 0) --------

@@ -121,9 +121,10 @@ int bm_pack_h2_job_fill(void* job, const float* src, void* dst, int G, int M, in
 int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, int max_nk, void* stream);
 /* amax slots and workspace: a slot is 8 floats whose maximum is max|x|; `amax_ws` is 16384 floats of scratch that
  * the producers of one stream may share.  bm_amax / bm_amax_checked overwrite the slot (per-workgroup partial maxima
- * in `amax_ws`, folded by a one-workgroup kernel).  The PRODUCERS (`amax_out` / `y_amax_out` arguments below) raise
- * the slot with atomic max: the caller hands them a ZEROED slot (bm_amax_is_atomic() == 1, the default; with
- * BM_AMAX_ATOMIC=0 in the environment they use the two-stage form as well and overwrite). */
+ * in `amax_ws`, folded by a one-workgroup kernel), and so do the PRODUCERS (`amax_out` / `y_amax_out` arguments
+ * below) by default.  With BM_AMAX_ATOMIC=1 in the environment (bm_amax_is_atomic() == 1; measured slower, kept as
+ * an A/B switch) the producers raise the slot with atomic max instead: the caller then hands them a ZEROED slot
+ * (hip_ops carves slots out of zeroed pools in either mode). */
 int bm_amax_ws_elems(void);
 int bm_amax_is_atomic(void);
 int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
@@ -202,6 +203,10 @@ int bm_softmax_bwd(const float* w, const float* dw, float* ds, long rows, int C,
 
 /* ---- ClipLoss (clip.hip)  bm/losses.py:77-114 ---- */
 int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_norm, void* stream);
+/* The same norms plus, in the same pass over the candidates: max |cand| raised into a ZEROED amax slot (nullable; the
+ * f16x2 scale of the score contraction) and the finiteness assert of bm/solver.py:258-260 (nullable device int). */
+int bm_clip_cand_prep(const float* cand, int Bc, long K, float* inv_norm, float* amax_slot, int* nonfinite_flag,
+                      void* stream);
 int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores, float* probs,
                float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
                void* stream);

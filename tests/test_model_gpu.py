@@ -532,8 +532,10 @@ def test_two_replicas_match_the_data_parallel_oracle(negatives):
         return SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
 
     sd0 = copy.deepcopy(build().state_dict())
-    batches = [[synthetic.make_batch(B, C, T, Fd, S, seed=50 + 10 * r + k, n_layouts=2) for k in range(steps + 1)]
-               for r in range(world)]
+    # one set of recordings for every batch: PositionGetter caches a layout per recording_index like the reference
+    recordings = synthetic.make_layouts(2, [C], torch.Generator().manual_seed(9))
+    batches = [[synthetic.make_batch(B, C, T, Fd, S, seed=50 + 10 * r + k, recordings=recordings)
+                for k in range(steps + 1)] for r in range(world)]
 
     def body(r):
         assert distrib.is_distributed() and distrib.world_size() == world and distrib.rank() == r
