@@ -43,8 +43,13 @@ __device__ __forceinline__ int bm_xcd_remap(int id, int n) {
 // Activations used by SimpleConv (bm/models/simpleconv.py:85-90).
 enum { BM_ACT_NONE = 0, BM_ACT_GELU = 1, BM_ACT_RELU = 2, BM_ACT_LEAKY = 3 };
 
+// erf: the library erff.  (A branch-free evaluation of both minimax polynomials of a faithfully-rounded erff --
+// 15 FMAs + one exp per element, no per-lane divergence -- was measured against it on the cfg2 step, same box,
+// interleaved: 0.15 ms per step SLOWER, profiles/r3_ab_notes.md.  The GELU passes are instruction-bound either way.)
+__device__ __forceinline__ float bm_erff(float a) { return erff(a); }
+
 __device__ __forceinline__ float bm_act(float z, int act, float leak) {
-    if (act == BM_ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+    if (act == BM_ACT_GELU) return 0.5f * z * (1.0f + bm_erff(z * 0.70710678118654752440f));
     if (act == BM_ACT_RELU) return z > 0.f ? z : 0.f;
     if (act == BM_ACT_LEAKY) return z > 0.f ? z : z * leak;
     return z;
@@ -52,7 +57,7 @@ __device__ __forceinline__ float bm_act(float z, int act, float leak) {
 
 __device__ __forceinline__ float bm_act_grad(float z, int act, float leak) {
     if (act == BM_ACT_GELU) {
-        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+        const float cdf = 0.5f * (1.0f + bm_erff(z * 0.70710678118654752440f));
         const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
         return cdf + z * pdf;
     }

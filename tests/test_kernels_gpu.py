@@ -417,6 +417,25 @@ def test_word_level_wer_batched(H, n_neg):
 
 
 @pytest.mark.gpu
+def test_gelu_and_its_derivative_pointwise(H):
+    """nn.GELU() (exact erf form, bm/models/simpleconv.py:85-86) and its derivative, element by element against
+    fp64: with a faithful fp32 erf the only error left is that of the reference's own fp32 formula
+    0.5 x (1 + erf(x / sqrt 2)) -- about one ulp of |x|."""
+    x = torch.cat([torch.linspace(-9, 9, 36001), torch.tensor([0.0, -0.0, 1e-30, -1e-20, 0.927734375 * 2 ** 0.5,
+                                                                  -0.927734375 * 2 ** 0.5, 30.0, -30.0])])
+    n = x.numel() - x.numel() % 4
+    x = x[:n].view(1, 1, n).contiguous()
+    y = H.affine_act_res(x.cuda(), None, None, None, H.ACT_GELU).double().cpu()
+    xd = x.double()
+    ref = 0.5 * xd * (1 + torch.erf(xd / 2 ** 0.5))
+    assert bool(((y - ref).abs() <= 1.3e-7 * xd.abs().clamp(min=1e-30)).all()), ((y - ref).abs() / xd.abs().clamp(min=1e-30)).max()
+    ones = torch.ones_like(x).cuda()
+    dy, _, _, _ = H.act_bn_bwd(ones, x.cuda(), None, None, None, None, False, H.ACT_GELU, want_dbias=False)
+    dref = 0.5 * (1 + torch.erf(xd / 2 ** 0.5)) + xd * torch.exp(-0.5 * xd * xd) / (2 * torch.pi) ** 0.5
+    assert float((dy.double().cpu() - dref).abs().max()) < 4e-7
+
+
+@pytest.mark.gpu
 def test_retrieval_rules_against_reference_fixture(H):
     """The batched GPU retrieval evaluation against numbers produced by the reference's own functions
     (scripts/run_eval_probs.py:237-264, bm/wer.py:82-121 executed from source: tests/golden/retrieval_rules.npz)."""
