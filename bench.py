@@ -407,7 +407,7 @@ def main():
         torch.cuda.synchronize()
         return distrib.max_over_ranks(time.perf_counter() - t0), loss
 
-    prefetch = negatives == "node" and world > 1
+    prefetch = negatives == "node" and distrib.is_distributed()       # (also under BM_FORCE_DISTRIBUTED=1 at world 1)
     for _ in range(args.warmup):
         cur, nxt = stream.next()
         solver.train_step(cur, next_batch=nxt if prefetch else None)

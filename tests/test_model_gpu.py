@@ -407,13 +407,17 @@ from brainmagick_amd.solver import Solver
 cfg = dict(depth=4, kernel_size=3, dilation_period=5, batch_norm=True, skip=True, gelu=True, glu=2,
            glu_context=1, complex_out=True, merger=True, merger_pos_dim=128, merger_channels=24,
            merger_dropout=0.0, initial_linear=24, subject_layers=True, subject_dim=0)
-def run(negatives):
+def run(negatives, prefetch=False):
     torch.manual_seed(0)
     model = SimpleConv(in_channels={"meg": 30}, out_channels=12, hidden={"meg": 32}, n_subjects=4, **cfg)
     solver = Solver(model, negatives=negatives)
     sb = synthetic.make_batch(8, 30, 64, 12, 4, seed=3)
-    losses = [float(solver.train_step(sb)) for _ in range(3)]
-    sd = solver.optimizer.state_dict()          # gathers the sharded moments
+    if prefetch:      # the next step's candidate all-gather is issued between this step's loss and backward
+        copies = [sb.replace() for _ in range(4)]
+        losses = [float(solver.train_step(copies[k], next_batch=copies[k + 1])) for k in range(3)]
+    else:
+        losses = [float(solver.train_step(sb)) for _ in range(3)]
+    sd = solver.state_dict()["optimizer"]       # gathers the sharded moments (collective)
     return losses, solver.optimizer.flat_param.clone(), sd["state"][0]["exp_avg"].clone(), \
         model.state_dict()["encoders.meg.sequence.0.1.running_var"].clone()
 plain = run("local")          # before init: world_size 1, no collectives
@@ -422,9 +426,11 @@ distrib.init(backend)
 assert distrib.is_distributed() and distrib.world_size() == 1
 assert distrib.comm_kind() == {"rccl": "rccl/c-abi", "nccl": "torch.distributed/nccl"}[backend]
 coll = run("node")            # reduce-scatter / all-gather / candidate gather / buffer all-reduce on RCCL
-assert plain[0] == coll[0], (plain[0], coll[0])
-for a, b in zip(plain[1:], coll[1:]):
-    assert torch.equal(a, b)
+ahead = run("node", prefetch=True)
+for other in (coll, ahead):
+    assert plain[0] == other[0], (plain[0], other[0])
+    for a, b in zip(plain[1:], other[1:]):
+        assert torch.equal(a, b)
 m = distrib.average_metrics({"loss": 2.0}, 3)
 assert abs(m["loss"] - 2.0) < 1e-6
 assert distrib.max_over_ranks(1.5) == 1.5
