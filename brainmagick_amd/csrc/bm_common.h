@@ -131,6 +131,8 @@ __device__ __forceinline__ float bm_amax_load(const float* slot) {
 }
 // host: reduce n partial maxima (ws) into the slot `out`; no-op when out is null
 int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream);
+// host: fold partials laid out [nsplit][C] into the slot AND into per-channel maxima rows_out[C] (nullable)
+int bm_amax_finalize_rows(const float* ws, int C, int nsplit, float* out, float* rows_out, hipStream_t stream);
 // host: destination of a producer's maximum for the current mode, and what follows its launch
 int bm_amax_atomic();                                   // 1 only with BM_AMAX_ATOMIC=1 (measured slower, core.hip)
 static inline BmAmaxDst bm_amax_dst(float* amax_out, float* amax_ws) {

@@ -52,6 +52,36 @@ int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream) {
     return bm_check_launch("amax_finalize");
 }
 
+// Partials laid out [nsplit][C] (the (channel, split) grids of the BatchNorm / GLU backward kernels): rows_out[c] =
+// max over the splits -- the per-channel maxima that give every row of a weight gradient its own f16x2 scale
+// (gemm_nt_h2w.hip, RS kernels) -- and the tensor maximum into the slot, in ONE one-workgroup launch.
+__global__ __launch_bounds__(1024) void amax_finalize_rows_kernel(const float* __restrict__ ws, int C, int nsplit,
+                                                                  float* __restrict__ out, float* __restrict__ rows_out) {
+    __shared__ float sh[16];
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        float r = 0.f;
+        for (int s = 0; s < nsplit; ++s) r = fmaxf(r, ws[(long)s * C + c]);
+        if (rows_out) rows_out[c] = r;
+        m = fmaxf(m, r);
+    }
+    m = bm_wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < BM_AMAX_SHARDS) {
+        float v = 0.f;
+        if (threadIdx.x == 0)
+            for (int w = 0; w < 16; ++w) v = fmaxf(v, sh[w]);
+        out[threadIdx.x] = v;
+    }
+}
+
+int bm_amax_finalize_rows(const float* ws, int C, int nsplit, float* out, float* rows_out, hipStream_t stream) {
+    if (!out) return BM_OK;
+    hipLaunchKernelGGL(amax_finalize_rows_kernel, dim3(1), dim3(1024), 0, stream, ws, C, nsplit, out, rows_out);
+    return bm_check_launch("amax_finalize_rows");
+}
+
 extern "C" int bm_amax_ws_elems(void) { return BM_AMAX_WS; }
 
 // Producers store per-workgroup partial maxima that a one-workgroup finalize launch folds (default), or raise a

@@ -50,6 +50,7 @@ struct GemmNTArgsH {
     const float* a; long a_sstride; long a_rstride;
     const float* x; long x_sstride; long x_rstride;
     const float* a_amax; const float* x_amax;
+    const float* a_row_amax;      // RS kernels: [M] per-row max |a| (the rows of dW factor out of the contraction)
     float* part;
     int S, M, Cn, T, dil, nsplit;
     int tiles_m, tiles_c;
@@ -157,7 +158,12 @@ extern "C" int bm_debug_trace_read(long long* out) {
 #define HG_T(I_)
 #endif
 
-template <int KS, int MW, int NS>
+// RS ("row scales"): every row of A carries its own power-of-two scale, taken from a per-row maximum that the
+// producer of A published (act_bn_bwd / glu_bwd: one gradient channel = one row of dW).  A channel far below its
+// tensor's maximum then keeps its 22 bits.  Needs T % 4 == 0: a 4-sample piece is then entirely
+// inside or outside a row, pieces outside are fetched at an out-of-range offset (zeros), and A needs no per-value
+// edge scales.
+template <int KS, int MW, int NS, bool RS = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     static_assert((MW == 5 && NS == 3) || (MW == 4 && NS == 2), "tile variants: 320 x 192, 256 x 128");
     static_assert(KS == 1 || NS == 3, "3 taps use the 3 slots");
@@ -236,11 +242,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     // last chunk also brings samples of the neighbouring rows; v_mul_legacy: 0 * anything = 0).  Rewritten only
     // when the chunk in the staging set is the first or last one of its segment, or follows one.
     float sva[4], svx[NXS][4];
+    float sarow[RS ? NA : 1];                          // RS: scale of the row of A piece i
+    if constexpr (RS) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + 32 * i + row32;
+            float inv_unused;
+            hg_scale_from_amax(m < a.M ? a.a_row_amax[m] : 0.f, sarow[i], inv_unused);
+        }
+    }
 #define HG_SET_SCALES(T0_)                                                                        \
     {                                                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                           \
             const int ta = (T0_) + 4 * pl + r;                                                    \
-            sva[r] = ta < a.T ? sa : 0.f;                                                         \
+            if constexpr (!RS) sva[r] = ta < a.T ? sa : 0.f;                                      \
             _Pragma("unroll") for (int j = 0; j < NXS; ++j) {                                     \
                 const int tx = ta + (KS == 3 ? (j - 1) * a.dil : 0);                              \
                 svx[j][r] = (tx >= 0 && tx < a.T) ? sx : 0.f;                                     \
@@ -255,9 +270,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     __amdgpu_buffer_rsrc_t qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);
     __amdgpu_buffer_rsrc_t qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);
     int vn, vx[NXS];                                   // byte offset of the chunk to fetch (X: per tap)
+    unsigned vna = 0;                                  // RS: the same for A, out of range when this lane's piece lies past T
 #define HG_CHUNK_OFFSETS()                                                                        \
     {                                                                                             \
         vn = ld_c * (HG_K * 4);                                                                   \
+        if constexpr (RS) vna = (ld_c * HG_K + 4 * pl < a.T) ? (unsigned)vn : 0x7f000000u;        \
         _Pragma("unroll") for (int j = 0; j < NXS; ++j) vx[j] = vn + (KS == 3 ? (j - 1) * a.dil * 4 : 0); \
     }
 #define HG_ADVANCE()                                                                              \
@@ -275,7 +292,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #define HG_Q(I_) ((I_) < NA ? 0 : (I_) - NA)     /* X piece index of staging piece I_ */
 #define HG_FETCH(I_)                                                                              \
     {                                                                                             \
-        if ((I_) < NA) rp[I_] = hg_ld128(qa, offa[(I_) < NA ? (I_) : 0] + vn, 0);                 \
+        if ((I_) < NA) rp[I_] = hg_ld128(qa, RS ? (int)((unsigned)offa[(I_) < NA ? (I_) : 0] + vna)             \
+                                                : offa[(I_) < NA ? (I_) : 0] + vn, 0);            \
         else {                                                                                    \
             const int vo_ = offx[(I_) < NA ? 0 : (I_) - NA] + vx[KS == 3 ? (HG_Q(I_) >> 1) % NXS : 0]; \
             rp[I_] = hg_ld128(qx, vo_, 0);                                                        \
@@ -290,8 +308,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     // piece I_ of the staging set -> stage buffer at byte address WB_, in three sub-steps that go behind three
     // consecutive MFMAs: split of samples 0-1, of samples 2-3, two 8-byte LDS writes (+ the fetch that refills it)
 #define HG_SV(I_) ((I_) < NA ? sva : svx[KS == 3 ? (HG_Q(I_) >> 1) % NXS : 0])
-#define HG_SPLIT0(I_) hg_split_pair(__uint_as_float(rp[I_][0]), __uint_as_float(rp[I_][1]), HG_SV(I_)[0], HG_SV(I_)[1], ph[0], pw[0]);
-#define HG_SPLIT1(I_) hg_split_pair(__uint_as_float(rp[I_][2]), __uint_as_float(rp[I_][3]), HG_SV(I_)[2], HG_SV(I_)[3], ph[1], pw[1]);
+#define HG_S(I_, R_) ((RS && (I_) < NA) ? sarow[(RS && (I_) < NA) ? (I_) : 0] : HG_SV(I_)[R_])
+#define HG_SPLIT0(I_) hg_split_pair(__uint_as_float(rp[I_][0]), __uint_as_float(rp[I_][1]), HG_S(I_, 0), HG_S(I_, 1), ph[0], pw[0]);
+#define HG_SPLIT1(I_) hg_split_pair(__uint_as_float(rp[I_][2]), __uint_as_float(rp[I_][3]), HG_S(I_, 2), HG_S(I_, 3), ph[1], pw[1]);
 #define HG_WRITE(I_, WB_)                                                                         \
     {                                                                                             \
         char* dst_ = (WB_) + ((I_) < NA ? ldsa + (I_) * 32 * 16                                   \
@@ -425,6 +444,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #undef HG_Q
 #undef HG_STORE
 #undef HG_SV
+#undef HG_S
 #undef HG_SPLIT0
 #undef HG_SPLIT1
 #undef HG_WRITE
@@ -435,15 +455,26 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 
     // partial tile out (inverse scales are exact powers of two): KS = 3: part[split][m][c * 3 + j];
     // KS = 1: part[split][m][c0 + 64 j + ...]
-    const float f = sa_inv * sx_inv;
     const long N = (long)a.Cn * KS;
     float* dst = a.part + (long)split * a.M * N;
+    if constexpr (RS) {
+        // the rows' inverse scales, once per workgroup into the (now free) LDS: 80 rows per lane below
+        __syncthreads();
+        for (int i = tid; i < BM; i += 256) {
+            float s_unused, inv_m = 0.f;
+            if (m0 + i < a.M) hg_scale_from_amax(a.a_row_amax[m0 + i], s_unused, inv_m);
+            smem[i] = inv_m;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * (MW * 32) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m < a.M) {
+                float f = sa_inv * sx_inv;
+                if constexpr (RS) f = smem[m - m0] * sx_inv;
                 if (KS == 3) {
                     const int c = c0 + wc * 32 + nl;
                     if (c < a.Cn) {
@@ -507,13 +538,13 @@ extern "C" int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T)
     return (int)want;
 }
 
-template <int KS, int MW, int NS>
+template <int KS, int MW, int NS, bool RS = false>
 static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     constexpr int PLANE = 4 * (64 * MW + 2) + NS * 4 * HG_XQ;
     const size_t lds = (size_t)2 * 2 * PLANE * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_h2w_kernel<KS, MW, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_h2w_kernel<KS, MW, NS, RS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt_h2w: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -521,7 +552,7 @@ static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     g.tiles_m = cdiv(g.M, 64 * MW);
     g.tiles_c = cdiv(g.Cn, KS == 3 ? 64 : 64 * NS);
     const long nblocks = (long)g.tiles_m * g.tiles_c * g.nsplit;
-    hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS, RS>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
     return bm_check_launch("gemm_nt_h2w");
 }
 
@@ -529,12 +560,9 @@ extern "C" int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, con
                              long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M, int Cn,
                              int T, int KS, int dil, int nsplit, void* stream);
 
-// part[split][m][c*KS + j] for one group of S consecutive segments (same contract as bm_gemm_nt without
-// order / seg); a_amax / x_amax: device pointers to max|a|, max|x| (bm_amax).  Only shapes
-// bm_gemm_nt_h2_covers() accepts.
-extern "C" int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* x,
-                             long x_sstride, long x_rstride, const float* x_amax, float* part, int S, int M, int Cn,
-                             int T, int KS, int dil, int nsplit, void* stream) {
+static int gemm_nt_h2_impl(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* a_row_amax,
+                           const float* x, long x_sstride, long x_rstride, const float* x_amax, float* part, int S,
+                           int M, int Cn, int T, int KS, int dil, int nsplit, void* stream) {
     BM_REQUIRE(a && x && part && a_amax && x_amax, "gemm_nt_h2: null pointer");
     BM_REQUIRE(M > 0 && Cn > 0 && T > 0 && nsplit > 0 && S >= 0, "gemm_nt_h2: bad dims");
     const int fam = hg_family(S, 1, M, Cn, T, KS, dil, false);
@@ -547,8 +575,33 @@ extern "C" int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, con
     GemmNTArgsH g;
     g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride; g.a_amax = a_amax;
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride; g.x_amax = x_amax;
+    g.a_row_amax = a_row_amax;
     g.part = part; g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit;
     hipStream_t s = (hipStream_t)stream;
-    if (KS == 3) return launch_gemm_nt_h2w<3, 5, 3>(g, s);
-    return fam == 2 ? launch_gemm_nt_h2w<1, 4, 2>(g, s) : launch_gemm_nt_h2w<1, 5, 3>(g, s);
+    // per-row scales of A: the 320-row tiles, rows contiguous in time (pieces of 4 samples never straddle a row)
+    const bool rs = a_row_amax && fam == 1 && T % 4 == 0 && a_rstride % 4 == 0 && a_sstride % 4 == 0;
+    if (KS == 3) return rs ? launch_gemm_nt_h2w<3, 5, 3, true>(g, s) : launch_gemm_nt_h2w<3, 5, 3>(g, s);
+    if (fam == 2) return launch_gemm_nt_h2w<1, 4, 2>(g, s);
+    return rs ? launch_gemm_nt_h2w<1, 5, 3, true>(g, s) : launch_gemm_nt_h2w<1, 5, 3>(g, s);
+}
+
+// part[split][m][c*KS + j] for one group of S consecutive segments (same contract as bm_gemm_nt without
+// order / seg); a_amax / x_amax: device pointers to max|a|, max|x| (bm_amax).  Only shapes
+// bm_gemm_nt_h2_covers() accepts.
+extern "C" int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* x,
+                             long x_sstride, long x_rstride, const float* x_amax, float* part, int S, int M, int Cn,
+                             int T, int KS, int dil, int nsplit, void* stream) {
+    return gemm_nt_h2_impl(a, a_sstride, a_rstride, a_amax, nullptr, x, x_sstride, x_rstride, x_amax, part, S, M, Cn, T,
+                           KS, dil, nsplit, stream);
+}
+
+// The same with `a_row_amax` ([M] floats, device; nullable): per-row max |a| -- every row of A (one gradient channel =
+// one row of dW) then carries its own scale, so a channel far below its tensor's maximum keeps full accuracy.
+// Used by the 320-row tile family when T % 4 == 0; ignored otherwise (the per-tensor scale applies).
+extern "C" int bm_gemm_nt_h2_rows(const float* a, long a_sstride, long a_rstride, const float* a_amax,
+                                  const float* a_row_amax, const float* x, long x_sstride, long x_rstride,
+                                  const float* x_amax, float* part, int S, int M, int Cn, int T, int KS, int dil,
+                                  int nsplit, void* stream) {
+    return gemm_nt_h2_impl(a, a_sstride, a_rstride, a_amax, a_row_amax, x, x_sstride, x_rstride, x_amax, part, S, M, Cn,
+                           T, KS, dil, nsplit, stream);
 }

@@ -297,7 +297,7 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
                              const float* shift, const float* mean, const float* invstd,
                              int bn_train, float* dy, float* dgamma, float* dbeta, float* dbias,
                              void* workspace, long workspace_bytes, int B, int C, int T, int act,
-                             float leak, float* amax_out, float* amax_ws, void* stream) {
+                             float leak, float* amax_out, float* amax_ws, float* amax_rows_out, void* stream) {
     BM_REQUIRE(dout && y && dy, "act_bn_bwd: null pointer");
     BM_REQUIRE(!amax_out || amax_ws, "act_bn_bwd: amax_out needs the amax workspace");
     BM_REQUIRE(!amax_out || (long)C * bm_bwd_nsplit(B) <= BM_AMAX_WS, "act_bn_bwd: too many channels for the amax workspace");
@@ -332,6 +332,9 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dy_partial,
                            dbias, C, nsplit);
     if (int rc = bm_check_launch("act_bn_bwd")) return rc;
+    // the (channel, split) grid's partials are per channel already: one launch folds them into the tensor slot and
+    // the per-channel maxima (two-stage mode only)
+    if (amax_dst.ws) return bm_amax_finalize_rows(amax_dst.ws, C, nsplit, amax_out, amax_rows_out, s);
     return bm_amax_done(amax_dst, C * nsplit, amax_out, s);
 }
 
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                                                       BmAmaxDst amax_ws) {
     __shared__ double sh[4 * 2];
     __shared__ float amax_sh[4];
-    float amx = 0.f;
+    float amx = 0.f, amx_g = 0.f;                      // max |du| of the value row hch and of the gate row H + hch
     const int hch = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
@@ -532,12 +535,20 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
             og.v[i] = d.v[i] * a.v[i] * sgm * (1.f - sgm);
             sa += oa.v[i];
             sg += og.v[i];
-            amx = fmaxf(amx, fmaxf(fabsf(oa.v[i]), fabsf(og.v[i])));
+            amx = fmaxf(amx, fabsf(oa.v[i]));
+            amx_g = fmaxf(amx_g, fabsf(og.v[i]));
         }
         oa.st(du + offa);
         og.st(du + offg);
     }
-    bm_publish_amax(amx, amax_ws, amax_sh);
+    if (amax_ws.ws) {
+        // two-stage mode: one partial per ROW of du, laid out [nsplit][2 H] (per-channel maxima, see bm_glu_bwd)
+        bm_publish_amax_at(amx, amax_ws, amax_sh, (unsigned)(split * 2 * H + hch));
+        __syncthreads();
+        bm_publish_amax_at(amx_g, amax_ws, amax_sh, (unsigned)(split * 2 * H + H + hch));
+    } else {
+        bm_publish_amax(fmaxf(amx, amx_g), amax_ws, amax_sh);
+    }
     double acc[2] = {(double)sa, (double)sg};
     block_sum<2>(acc, sh);
     if (threadIdx.x == 0 && partial) {
@@ -551,10 +562,11 @@ extern "C" long bm_glu_bwd_workspace_bytes(int B, int H) {
 }
 
 extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
-                          long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws, void* stream) {
+                          long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws,
+                          float* amax_rows_out, void* stream) {
     BM_REQUIRE(dout && u && du, "glu_bwd: null pointer");
     BM_REQUIRE(!amax_out || amax_ws, "glu_bwd: amax_out needs the amax workspace");
-    BM_REQUIRE(!amax_out || (long)H * bm_bwd_nsplit(B) <= BM_AMAX_WS, "glu_bwd: too many channels for the amax workspace");
+    BM_REQUIRE(!amax_out || (long)2 * H * bm_bwd_nsplit(B) <= BM_AMAX_WS, "glu_bwd: too many channels for the amax workspace");
     if ((long)B * H * T == 0) return BM_OK;
     const int nsplit = bm_bwd_nsplit(B);
     if (workspace_bytes < bm_glu_bwd_workspace_bytes(B, H))
@@ -572,5 +584,6 @@ extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* d
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, s, partial,
                            dbias, 2 * H, nsplit);
     if (int rc = bm_check_launch("glu_bwd")) return rc;
+    if (amax_dst.ws) return bm_amax_finalize_rows(amax_dst.ws, 2 * H, nsplit, amax_out, amax_rows_out, s);
     return bm_amax_done(amax_dst, H * nsplit, amax_out, s);
 }

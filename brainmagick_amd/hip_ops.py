@@ -144,6 +144,7 @@ def amax(x: torch.Tensor, nonfinite_flag: tp.Optional[torch.Tensor] = None) -> t
 
 
 _NO_PUBLISH = _os.environ.get("BM_NO_AMAX_PUBLISH", "0") == "1"     # A/B switch: stand-alone amax passes instead
+_ROW_SCALES = _os.environ.get("BM_ROW_SCALES", "1") == "1"          # A/B switch: per-row scales of dy in the weight gradients
 _amax_pool: tp.Dict[torch.device, tp.List[tp.Any]] = {}
 _amax_workspaces: tp.Dict[tp.Any, torch.Tensor] = {}
 
@@ -174,6 +175,25 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
     return slot
 
 
+def _row_amax_out(t: torch.Tensor, slot) -> tp.Optional[torch.Tensor]:
+    """[channels] fp32 buffer for a producer with a (channel, split) grid to publish max|t| PER CHANNEL into (next to the
+    tensor slot; two-stage amax mode only).  A gradient channel is a row of the weight gradient: the f16x2 weight-gradient
+    kernel then scales A row by row (csrc/gemm_nt_h2w.hip, RS kernels), so a channel far below its tensor's maximum keeps
+    its 22 bits.  Attached to the tensor like the slot."""
+    if slot is None or lib().bm_amax_is_atomic():
+        return None
+    rows = torch.empty(t.shape[1], device=t.device, dtype=torch.float32)
+    t._bm_row_amax = (t._version, t.data_ptr(), rows)
+    return rows
+
+
+def row_amax_of(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
+    cached = getattr(t, "_bm_row_amax", None)
+    if cached is not None and cached[0] == t._version and cached[1] == t.data_ptr():
+        return cached[2]
+    return None
+
+
 def _slot_args(slot):
     """(amax_out, amax_ws) arguments of a producer."""
     return (_p(slot), _p(_amax_ws(slot.device)) if slot is not None else None)
@@ -182,11 +202,12 @@ def _slot_args(slot):
 def _touched(t: torch.Tensor) -> torch.Tensor:
     """Called by every wrapper that lets a library kernel write INTO an existing tensor through its raw pointer:
     torch's version counter does not see such writes, so a maximum published for the old contents must go."""
-    if getattr(t, "_bm_amax", None) is not None:
-        try:
-            del t._bm_amax
-        except AttributeError:
-            pass
+    for attr in ("_bm_amax", "_bm_row_amax", "_bm_inv_norms"):
+        if getattr(t, attr, None) is not None:
+            try:
+                delattr(t, attr)
+            except AttributeError:
+                pass
     return t
 
 
@@ -498,11 +519,14 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
     if mode == "f16x2":
         a_amax, x_amax = amax(a), amax(x)
+        a_rows = row_amax_of(a) if _ROW_SCALES else None       # published by the producer of `a` (act_bn_bwd / glu_bwd)
+        if a_rows is not None and a_rows.numel() != M:
+            a_rows = None
 
         def launch():
-            check(lib().bm_gemm_nt_h2(_p(a), a_strides[0], a_strides[1], _p(a_amax), _p(x), x_strides[0],
-                                      x_strides[1], _p(x_amax), _p(part), S, M, Cn, T, KS, dil, nsplit,
-                                      _stream()), "bm_gemm_nt_h2")
+            check(lib().bm_gemm_nt_h2_rows(_p(a), a_strides[0], a_strides[1], _p(a_amax), _p(a_rows), _p(x),
+                                           x_strides[0], x_strides[1], _p(x_amax), _p(part), S, M, Cn, T, KS, dil,
+                                           nsplit, _stream()), "bm_gemm_nt_h2")
     else:
         fn = {"f32": lib().bm_gemm_nt, "bf16": lib().bm_gemm_nt_bf16, "f32x3": lib().bm_gemm_nt_x3}[mode]
 
@@ -612,10 +636,11 @@ def act_bn_bwd(dout, y, scale, shift, mean, invstd, bn_train: bool, act: int, le
     dbias = torch.empty(C, device=y.device, dtype=torch.float32) if want_dbias else None
     nbytes = lib().bm_act_bn_bwd_workspace_bytes(B, C)
     ws = torch.empty(nbytes, device=y.device, dtype=torch.uint8)
+    slot = _amax_slot(dy)
     check(lib().bm_act_bn_bwd(_p(dout), _p(y), _p(_opt(scale, "scale")), _p(_opt(shift, "shift")),
                               _p(_opt(mean, "mean")), _p(_opt(invstd, "invstd")), int(bn_train),
                               _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), nbytes, B, C, T, act,
-                              leak, *_slot_args(_amax_slot(dy)), _stream()), "bm_act_bn_bwd")
+                              leak, *_slot_args(slot), _p(_row_amax_out(dy, slot)), _stream()), "bm_act_bn_bwd")
     return dy, dgamma, dbeta, dbias
 
 
@@ -665,8 +690,9 @@ def glu_bwd(dout: torch.Tensor, u: torch.Tensor, want_dbias: bool = True):
     dbias = torch.empty(C2, device=u.device, dtype=torch.float32) if want_dbias else None
     nbytes = lib().bm_glu_bwd_workspace_bytes(B, H)
     ws = torch.empty(nbytes, device=u.device, dtype=torch.uint8)
+    slot = _amax_slot(du)
     check(lib().bm_glu_bwd(_p(dout), _p(u), _p(du), _p(dbias), _p(ws), nbytes, B, H, T,
-                           *_slot_args(_amax_slot(du)), _stream()), "bm_glu_bwd")
+                           *_slot_args(slot), _p(_row_amax_out(du, slot)), _stream()), "bm_glu_bwd")
     return du, dbias
 
 

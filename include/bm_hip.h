@@ -145,6 +145,11 @@ int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T);
 int bm_gemm_nt_h2(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* x,
                   long x_sstride, long x_rstride, const float* x_amax, float* part, int S, int M, int Cn, int T,
                   int KS, int dil, int nsplit, void* stream);
+/* The same with per-row maxima of `a` ([M] floats, nullable): every row of A -- one gradient channel = one row of dW --
+ * carries its own power-of-two scale (320-row tile family, T % 4 == 0; otherwise the per-tensor scale applies). */
+int bm_gemm_nt_h2_rows(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* a_row_amax,
+                       const float* x, long x_sstride, long x_rstride, const float* x_amax, float* part, int S,
+                       int M, int Cn, int T, int KS, int dil, int nsplit, void* stream);
 
 /* ---- time-contraction GEMM, fp32 MFMA, split-K (gemm_nt.hip) ----
  * part[g,split][m][c*KS+j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j-KS/2)*dil].
@@ -165,7 +170,9 @@ int bm_bn_eval_affine(int C, const float* gamma, const float* beta, const float*
                       const float* running_var, float eps, float* mean, float* invstd, float* scale,
                       float* shift, void* stream);
 /* `amax_out` (nullable amax slot) + `amax_ws` on the elementwise producers: the slot receives max|output|, the
- * f16x2 scale of the contraction that consumes the tensor -- saves a separate bm_amax pass over it. */
+ * f16x2 scale of the contraction that consumes the tensor -- saves a separate bm_amax pass over it.
+ * `amax_rows_out` (bm_act_bn_bwd / bm_glu_bwd; nullable, [C] resp. [2 H] floats): max |output| per CHANNEL -- a
+ * gradient channel is a row of the weight gradient, which bm_gemm_nt_h2_rows scales row by row. */
 int bm_affine_act_res(const float* y, const float* scale, const float* shift, const float* res,
                       float* out, int B, int C, int T, int act, float leak, float* amax_out, float* amax_ws,
                       void* stream);
@@ -174,7 +181,8 @@ long bm_act_bn_bwd_workspace_bytes(int B, int C);
 int bm_act_bn_bwd(const float* dout, const float* y, const float* scale, const float* shift,
                   const float* mean, const float* invstd, int bn_train, float* dy, float* dgamma,
                   float* dbeta, float* dbias, void* workspace, long workspace_bytes, int B, int C,
-                  int T, int act, float leak, float* amax_out, float* amax_ws, void* stream);
+                  int T, int act, float leak, float* amax_out, float* amax_ws, float* amax_rows_out,
+                  void* stream);
 long bm_channel_sum_workspace_bytes(int B, int C);
 int bm_channel_sum(const float* x, long bstride, float* out, void* workspace, long workspace_bytes,
                    int B, int C, int T, void* stream);
@@ -184,7 +192,8 @@ int bm_channel_stats(const float* x, float* stats, int B, int C, int T, void* st
 int bm_glu_fwd(const float* u, float* out, int B, int H, int T, float* amax_out, float* amax_ws, void* stream);
 long bm_glu_bwd_workspace_bytes(int B, int H);
 int bm_glu_bwd(const float* dout, const float* u, float* du, float* dbias, void* workspace,
-               long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws, void* stream);
+               long workspace_bytes, int B, int H, int T, float* amax_out, float* amax_ws,
+               float* amax_rows_out, void* stream);
 /* out[c][b] = sum_t x[b][c][t]  (per-segment time sums, transposed; bias gradient of the composed front end:
  * bm/models/simpleconv.py:113-120 + bm/models/common.py:55-58 chained) */
 int bm_time_sums_t(const float* x, float* out, int B, int C, int T, void* stream);

@@ -144,9 +144,11 @@ def test_dynamic_range_is_handled_by_the_scales(h2_mode, H, xs, ws):
 # subnormals (spacing 2^-24 in scaled units) and the ABSOLUTE error stays <= 2^-39 max|tensor|.
 #  * conv: a channel-wise relative bound holds whenever an output channel is not fed EXCLUSIVELY by inputs that are
 #    more than 2^-16 below the tensor maximum: |err(y[m])| <= 2^-38 max|x| sum|w[m]| + the fp32 accumulation error;
-#  * weight gradient: dW row m only sees dy channel m (and column c only x channel c), so a channel d decades below
-#    its tensor's maximum has row-wise relative error <= max(fp32-class, 2^-37 * 10^d).  Rows within 2^-16 of the
-#    maximum -- 4.8 decades; BatchNorm'ed activations and their gradients span one or two -- are fp32-class.
+#  * weight gradient: dW row m only sees dy channel m (and column c only x channel c), so with ONE scale per tensor a
+#    channel d decades below its tensor's maximum has row-wise relative error <= max(fp32-class, 2^-37 * 10^d); rows
+#    within 2^-16 of the maximum -- 4.8 decades -- are fp32-class.  The gradients that reach the weight-gradient kernel
+#    from the BatchNorm / GLU backward kernels carry PER-CHANNEL maxima: then every row has its own scale and is
+#    fp32-class whatever the spread (case (b) below); the x side keeps the per-tensor bound.
 H2_ABS = 2.0 ** -37
 
 
@@ -159,18 +161,51 @@ def test_per_channel_spread_weight_gradient_rows(h2_mode, H, decades):
     dy = torch.randn(B, M, T, generator=g) * sdy[None, :, None]
     x = torch.randn(B, Cin, T, generator=g) * sx[None, :, None]
     assert H.lib().bm_gemm_nt_h2_covers(M, Cin, KS, B, T, 1, dil, 0)
-    dw = H.gemm_nt(dy.cuda(), x.cuda(), B, M, Cin, T, KS, dil)[0].double().cpu()
     ref = _wgrad_ref(dy, x, KS, dil)
+    col_bound = torch.clamp(H2_ABS / sx.double(), min=2e-6)
+    dyg, xg = dy.cuda(), x.cuda()
+    # (a) one scale per tensor (a gradient tensor whose producer published no per-channel maxima)
+    dw = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil)[0].double().cpu()
     assert rel_l2(dw, ref) < 1e-6                                     # norm-wise: always fp32-class
     row_err = (dw - ref).norm(dim=(1, 2)) / ref.norm(dim=(1, 2))      # per dy channel
     col_err = (dw - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))      # per x channel
     row_bound = torch.clamp(H2_ABS / sdy.double(), min=2e-6)
-    col_bound = torch.clamp(H2_ABS / sx.double(), min=2e-6)
-    print(f"spread 1e-{decades}: worst dW row {row_err.max():.2e}, column {col_err.max():.2e} "
+    print(f"spread 1e-{decades}, tensor scale: worst dW row {row_err.max():.2e}, column {col_err.max():.2e} "
           f"(rows within 2^-16 of the maximum: {row_err[sdy >= 2.0 ** -16].max():.2e})")
     assert bool((row_err <= row_bound).all()), (row_err / row_bound).max().item()
     assert bool((col_err <= col_bound).all()), (col_err / col_bound).max().item()
     assert row_err[sdy >= 2.0 ** -16].max().item() < 2e-6 and col_err[sx >= 2.0 ** -16].max().item() < 2e-6
+    # (b) per-channel maxima of dy, as act_bn_bwd / glu_bwd publish them: every ROW of dW is fp32-class, whatever the
+    # spread between the channels (the column bound is unchanged: x keeps its per-tensor scale)
+    dyg._bm_row_amax = (dyg._version, dyg.data_ptr(), dyg.abs().amax(dim=(0, 2)).contiguous())
+    dw = H.gemm_nt(dyg, xg, B, M, Cin, T, KS, dil)[0].double().cpu()
+    row_err = (dw - ref).norm(dim=(1, 2)) / ref.norm(dim=(1, 2))
+    col_err = (dw - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))
+    print(f"spread 1e-{decades}, row scales:   worst dW row {row_err.max():.2e}, column {col_err.max():.2e}")
+    assert rel_l2(dw, ref) < 1e-6
+    assert row_err.max().item() < 2e-6, row_err.max().item()
+    # element-wise against the row's own magnitude for the x channels within 2^-16 of their maximum
+    ok_cols = sx >= 2.0 ** -16
+    el = ((dw - ref).abs().amax(dim=2)[:, ok_cols] / ref.abs().amax(dim=(1, 2))[:, None]).max().item()
+    assert el < 4e-6, el
+    assert bool((col_err <= col_bound).all()), (col_err / col_bound).max().item()
+
+
+@pytest.mark.parametrize("KS,T", [(1, 360), (3, 361), (3, 130)])
+def test_row_scaled_weight_gradient_shapes(h2_mode, H, KS, T):
+    """The row-scaled kernels on a 1x1 layer, and the fall-back to the per-tensor scale when T % 4 != 0 / short T."""
+    g = _gen(60 + KS + T)
+    B, Cin, M, dil = 3, 320, 320, 1
+    dy = torch.randn(B, M, T, generator=g) * torch.logspace(0, -5, M)[None, :, None]
+    x = torch.randn(B, Cin, T, generator=g)
+    dyg = dy.cuda()
+    dyg._bm_row_amax = (dyg._version, dyg.data_ptr(), dyg.abs().amax(dim=(0, 2)).contiguous())
+    dw = H.gemm_nt(dyg, x.cuda(), B, M, Cin, T, KS, dil)[0]
+    ref = _wgrad_ref(dy, x, KS, dil)
+    assert rel_l2(dw, ref) < GRAD_TOL
+    if T % 4 == 0:
+        row_err = (dw.double().cpu() - ref).norm(dim=(1, 2)) / ref.norm(dim=(1, 2))
+        assert row_err.max().item() < 2e-6, row_err.max().item()
 
 
 @pytest.mark.parametrize("decades", [0, 4, 8])
@@ -288,9 +323,11 @@ def test_producers_publish_their_own_maximum(h2_mode, H):
     assert published(o) == float(o.abs().max())
     du, _ = H.glu_bwd(o, u)
     assert published(du) == float(du.abs().max())
+    assert torch.equal(H.row_amax_of(du), du.abs().amax(dim=(0, 2)))           # per channel: rows of the weight gradient
     mean, invstd = torch.randn(C, generator=g).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
     dy, _, _, _ = H.act_bn_bwd(res, y, scale, shift, mean, invstd, True, H.ACT_GELU, want_affine_grads=True)
     assert published(dy) == float(dy.abs().max())
+    assert torch.equal(H.row_amax_of(dy), dy.abs().amax(dim=(0, 2)))
     w = (torch.randn(128, C, 3, generator=g) / 14).cuda()
     for kw in (dict(), dict(bias=shift.new_zeros(128), scale=scale.new_ones(128), shift=shift.new_zeros(128),
                              act=H.ACT_GELU, want_pre=True)):
