@@ -285,6 +285,18 @@ def clip_roofline(dev, mode, reps=20):
     return out
 
 
+def flush_c_stdio():
+    """librccl prints a version banner to the C-level stdout when the first communicator comes up; on a pipe that
+    text sits in the stdio buffer until exit and would land BEHIND the JSON line.  Flushing right after init (every
+    rank) and right before the result keeps the JSON line the last thing on stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def self_launch_command(gpus: int, argv, port=None):
     """(command, environment) of the re-launch under torch.distributed.run: one rank per GPU of this node,
     rendezvous on 127.0.0.1 (the container hostname may not resolve) on a free port."""
@@ -379,6 +391,7 @@ def main():
 
     hip_ops.set_compute_dtype(args.dtype)
     distrib.init()
+    flush_c_stdio()
     rank, world = distrib.rank(), distrib.world_size()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -507,8 +520,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
     distrib.barrier()
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

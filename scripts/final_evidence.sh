@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box call that produces the round's committed evidence: full GPU suite, smoke, default bench, rocprofv3
+# kernel stats + PMC passes, and the side benches (cfg3, cfg5, sustained, RCCL path forced at world size 1 with
+# whole-node negatives + prefetch).  Usage: scripts/final_evidence.sh <tag>
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R; mkdir -p gpurun_out
+TAG=${1:-final}
+bash scripts/gpu_check.sh $TAG 1500 prof 2>&1 | tail -30
+SIDE="--no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip"
+timeout 300 python bench.py --workload cfg3 $SIDE > gpurun_out/${TAG}_bench_cfg3.json 2>/dev/null; echo "cfg3 rc=$?"
+timeout 300 python bench.py --workload cfg5 $SIDE > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null; echo "cfg5 rc=$?"
+timeout 300 python bench.py --steps 200 --warmup 5 $SIDE > gpurun_out/${TAG}_bench_sustained_200steps.json 2>/dev/null; echo "sustained rc=$?"
+BM_FORCE_DISTRIBUTED=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29631 timeout 300 \
+  python bench.py --negatives node $SIDE > gpurun_out/${TAG}_bench_forced_rccl_world1_node.json 2>/dev/null; echo "forced rccl rc=$?"
+for f in cfg3 cfg5 sustained_200steps forced_rccl_world1_node; do
+  python - gpurun_out/${TAG}_bench_$f.json <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print(sys.argv[1].split("/")[-1], "ms/step", round(d["ms_per_step"], 3), "seg/s", round(d["value"]), d["config"].get("comm"), d["config"].get("negatives"), d["config"].get("candidate_gather"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done

@@ -114,6 +114,18 @@ def test_amax_kernel(H):
         assert float(got.max()) == float(x.abs().max())
     x = torch.zeros(64).cuda()
     assert float(H.amax(x).max()) == 0.0
+    # a tensor that is only 4-byte aligned (a batch slice such as meg[1:] with C * T odd): scalar head up to the first
+    # 16-byte boundary, vector body, scalar tail
+    for n, off in ((4099, 1), (4099, 3), (7, 2), (2, 1)):
+        base = torch.randn(n + 8, generator=g).cuda() * 2
+        view = base[off:off + n]
+        assert view.data_ptr() % 16 != 0 and view.is_contiguous()
+        assert float(H.amax(view).max()) == float(view.abs().max()), (n, off)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    bad = torch.randn(4099, generator=g).cuda()
+    bad[1] = float("inf")                       # inside the scalar head of the misaligned view below
+    H.amax(bad[1:], nonfinite_flag=flag)
+    assert int(flag) == 1
     # cached per tensor version: an in-place change invalidates the cache
     y = torch.ones(1000).cuda()
     a1 = H.amax(y)
