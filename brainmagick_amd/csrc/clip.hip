@@ -100,6 +100,26 @@ extern "C" int bm_clip_cand_prep(const float* cand, int Bc, long K, float* inv_n
     return bm_check_launch("clip_cand_prep");
 }
 
+// ClipLoss.forward asserts `mask.all()` (bm/losses.py:110) -- a host synchronisation in the middle of the step.  Under
+// the Solver the verdict goes to the device-side flag word instead: *flag |= 1 when any byte of the bool mask is 0.
+__global__ __launch_bounds__(256) void flag_unless_all_set_kernel(const unsigned char* __restrict__ mask, long n,
+                                                                  int* __restrict__ flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        bad |= mask[i] == 0;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int bm_flag_unless_all_set(const unsigned char* mask, long n, int* flag, void* stream) {
+    BM_REQUIRE(flag && (mask || n == 0) && n >= 0, "flag_unless_all_set: bad arguments");
+    if (n == 0) return BM_OK;
+    long blocks = (n + 255) / 256;
+    blocks = blocks > 512 ? 512 : blocks;
+    hipLaunchKernelGGL(flag_unless_all_set_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, n,
+                       flag);
+    return bm_check_launch("flag_unless_all_set");
+}
+
 // One workgroup (4 wavefronts) per estimate row b:
 //   scores[b][o] = inv_norm[o] * sum_split part[split][b][o]      (fixed split order: deterministic)
 //   loss_row[b]  = logsumexp_o(scores[b]) - scores[b][tgt], tgt = b + target_offset

@@ -23,15 +23,21 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _conv_weight_grads(dy, x, weight_shape, KS, dil, transposed_weight):
-    """dW in the layout of the parameter: Conv1d [M,Cin,KS] or ConvTranspose1d(k=1) [Cin,M,1]."""
+def _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight):
+    """dW in the layout of the parameter: Conv1d [M,Cin,KS] or ConvTranspose1d(k=1) [Cin,M,1]; written straight into
+    the optimizer's flat gradient bucket when the parameter has a registered destination (hip_ops.grad_destination)."""
     B, M, T = dy.shape
     Cin = x.shape[1]
+    dst = H.grad_destination(weight)
+    # (a registered destination is returned as a FRESH view: autograd only adopts a gradient tensor nobody else holds)
     if transposed_weight:
-        out = torch.empty(weight_shape, device=dy.device, dtype=torch.float32)   # [Cin, M, 1]
+        out = dst if dst is not None else torch.empty(weight.shape, device=dy.device, dtype=torch.float32)   # [Cin, M, 1]
         H.gemm_nt(dy, x, B, M, Cin, T, 1, 1, out=out, out_strides=(0, 1, M, 0))
-        return out
-    return H.gemm_nt(dy, x, B, M, Cin, T, KS, dil).view(weight_shape)
+        return out.view(weight.shape) if dst is not None else out
+    if dst is not None:
+        H.gemm_nt(dy, x, B, M, Cin, T, KS, dil, out=dst.view(1, M, Cin, KS))
+        return dst.view(weight.shape)
+    return H.gemm_nt(dy, x, B, M, Cin, T, KS, dil).view(weight.shape)
 
 
 class Conv1dFn(torch.autograd.Function):
@@ -84,7 +90,7 @@ class Conv1dFn(torch.autograd.Function):
                 M, Cin, _ = weight.shape
                 wp = H.pack_conv_dgrad(weight, (dy.shape[2], dil))
             _, dx, _ = H.conv_nn(dy, wp, Cin, KS, dil)
-        dw = _conv_weight_grads(dy, x, weight.shape, KS, dil, transposed_weight) \
+        dw = _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight) \
             if ctx.needs_input_grad[1] else None
         return dx, dw, dbias, None, None, None, None
 
@@ -135,10 +141,10 @@ class ConvBNActFn(torch.autograd.Function):
                                                 leak, want_affine_grads=True, want_dbias=has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
+            # dx feeds the previous layer's elementwise backward kernel: nobody needs its maximum
             _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight, (dy.shape[2], dil)), Cin, KS, dil,
-                                 res=dout if residual else None)
-        dw = H.gemm_nt(dy, x, x.shape[0], M, Cin, x.shape[2], KS, dil).view(weight.shape) \
-            if ctx.needs_input_grad[1] else None
+                                 res=dout if residual else None, publish_amax=False)
+        dw = _conv_weight_grads(dy, x, weight, KS, dil, False) if ctx.needs_input_grad[1] else None
         return (dx, dw, dbias, dgamma, dbeta) + (None,) * 10
 
 
@@ -163,9 +169,8 @@ class GLUConvFn(torch.autograd.Function):
         du, dbias = H.glu_bwd(_c(dout), u, want_dbias=ctx.has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
-            _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight, (du.shape[2], 1)), Cin, KS, 1)
-        dw = H.gemm_nt(du, x, x.shape[0], M, Cin, x.shape[2], KS, 1).view(weight.shape) \
-            if ctx.needs_input_grad[1] else None
+            _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight, (du.shape[2], 1)), Cin, KS, 1, publish_amax=False)
+        dw = _conv_weight_grads(du, x, weight, KS, 1, False) if ctx.needs_input_grad[1] else None
         return dx, dw, dbias
 
 

@@ -144,6 +144,7 @@ def amax(x: torch.Tensor, nonfinite_flag: tp.Optional[torch.Tensor] = None) -> t
 
 
 _NO_PUBLISH = _os.environ.get("BM_NO_AMAX_PUBLISH", "0") == "1"     # A/B switch: stand-alone amax passes instead
+_DIRECT_GRADS = _os.environ.get("BM_DIRECT_GRADS", "1") == "1"      # A/B switch: weight gradients written straight into the flat bucket
 _ROW_SCALES = _os.environ.get("BM_ROW_SCALES", "1") == "1"          # A/B switch: per-row scales of dy in the weight gradients
 _amax_pool: tp.Dict[torch.device, tp.List[tp.Any]] = {}
 _amax_workspaces: tp.Dict[tp.Any, torch.Tensor] = {}
@@ -362,11 +363,13 @@ def pack_conv_dgrad(weight: torch.Tensor, shape=None) -> torch.Tensor:
 def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: int = 1,
             widx: tp.Optional[torch.Tensor] = None, bias=None, scale=None, shift=None, res=None,
             act: int = ACT_NONE, leak: float = 0., want_pre: bool = False, want_out: bool = True,
-            want_stats: bool = False, out: tp.Optional[torch.Tensor] = None, bias_gstride: int = 0):
+            want_stats: bool = False, out: tp.Optional[torch.Tensor] = None, bias_gstride: int = 0,
+            publish_amax: bool = True):
     """Returns (y_pre | None, y_out | None, stats | None); x is [B, Cin, T].  ``out``: write y_out there instead of
     allocating (it may be ``res`` itself: every element is read and written by the same thread, which is how the
     ClipLoss backward accumulates over candidate blocks).  ``bias_gstride`` > 0: ``bias`` holds one vector per weight
-    group, ``bias_gstride`` floats apart, selected by ``widx`` like the weights."""
+    group, ``bias_gstride`` floats apart, selected by ``widx`` like the weights.  ``publish_amax=False``: the output
+    goes to an elementwise kernel (the data gradients of the conv stack), nobody needs its maximum."""
     _req(x, "conv_nn.x")
     mode = getattr(wpacked, "_bm_mode", "f32")      # set by pack_weights
     _req(wpacked, "conv_nn.w", {"f32": torch.float32, "f16x2": torch.uint8}.get(mode, torch.bfloat16))
@@ -391,7 +394,7 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
               KS, dil, act, leak)
     if mode == "f16x2":
         x_amax = amax(x)
-        y_slot = _amax_slot(y_out) if y_out is not None else None
+        y_slot = _amax_slot(y_out) if (y_out is not None and publish_amax) else None
 
         def launch():
             check(lib().bm_conv1d_nn_h2(_p(x), Cin * T, _p(x_amax), _p(wpacked), *common, wpacked._bm_groups,
@@ -543,6 +546,18 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         check(lib().bm_reduce_splits(_p(part), _p(out), G, nsplit, M, Cn, KS, *out_strides,
                                      _stream()), "bm_reduce_splits")
     return out
+
+
+def grad_destination(param: torch.Tensor) -> tp.Optional[torch.Tensor]:
+    """Where the weight gradient of ``param`` may be written directly: its view of the optimizer's flat gradient bucket
+    (``FlatAdam`` registers it as ``param._bm_grad_dst``), handed out ONCE per ``zero_grad`` -- a parameter that
+    takes part in the graph twice gets a fresh tensor the second time, and autograd accumulates as usual.  The
+    returned view becomes ``param.grad`` without a copy (``FlatAdam.collect_grads`` recognises the address)."""
+    dst = getattr(param, "_bm_grad_dst", None)
+    if dst is None or dst[1][0] or param.grad is not None or not _DIRECT_GRADS:
+        return None
+    dst[1][0] = True
+    return dst[0]
 
 
 def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
@@ -753,6 +768,13 @@ def clip_inv_norms(cand: torch.Tensor, nonfinite_flag: tp.Optional[torch.Tensor]
     except Exception:
         pass
     return out
+
+
+def flag_unless_all_set(mask: torch.Tensor, flag: torch.Tensor) -> None:
+    """flag[0] |= 1 (device side, no sync) when the bool ``mask`` holds a False."""
+    _req(mask, "flag_unless_all_set.mask", torch.bool)
+    check(lib().bm_flag_unless_all_set(_p(mask), mask.numel(), _p(_req(flag, "flag", torch.int32)), _stream()),
+          "bm_flag_unless_all_set")
 
 
 def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,

@@ -79,11 +79,12 @@ class ClipLoss(torch.nn.Module):
         negatives (losses.py:104-114).  ``target_offset`` (extension, default 0 = reference
         behaviour) shifts the targets to candidates [offset, offset+B): a data-parallel rank uses
         it to point at its own block of the whole-node gathered candidates."""
-        if self.defer_mask_check and mask.is_cuda:
+        if self.defer_mask_check and mask.is_cuda and mask.dtype == torch.bool:
             # Solver: the reference's assert costs a host sync in the middle of the step; the verdict is OR-ed into
             # the device-side flag word and raised at the next step's single synchronisation point
             from . import hip_ops as H
-            H.index_error_flag(mask.device)[2:3].bitwise_or_((~mask.all()).to(torch.int32).view(1))
+            H.flag_unless_all_set(mask if mask.is_contiguous() else mask.contiguous(),
+                                  H.index_error_flag(mask.device)[2:3])
         else:
             assert mask.all(), "mask is not supported for now"
         assert estimate.size(0) + target_offset <= candidate.size(0), \

@@ -93,8 +93,14 @@ class FlatAdam(torch.optim.Optimizer):
         autograd then hands over its gradient tensors and ``collect_grads()`` moves them into the bucket with one
         multi-tensor copy -- what the Solver does every step."""
         if set_to_none:
-            for p in self.params:
+            for p, off in zip(self.params, self.offsets):
                 p.grad = None
+                # the weight-gradient kernels may write straight into the bucket (hip_ops.grad_destination)
+                dst = getattr(p, "_bm_grad_dst", None)
+                if dst is None or dst[0].data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                    p._bm_grad_dst = (self.flat_grad[off:off + p.numel()].view(p.shape), [False])
+                else:
+                    dst[1][0] = False
             return
         self.flat_grad.zero_()
         self._attach_views()

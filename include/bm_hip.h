@@ -216,6 +216,9 @@ int bm_clip_inv_norms(const float* cand, int Bc, long K, float* inv_norm, void* 
  * f16x2 scale of the score contraction) and the finiteness assert of bm/solver.py:258-260 (nullable device int). */
 int bm_clip_cand_prep(const float* cand, int Bc, long K, float* inv_norm, float* amax_slot, int* nonfinite_flag,
                       void* stream);
+/* *flag |= 1 when any byte of the bool mask is 0: ClipLoss.forward's `assert mask.all()` (bm/losses.py:110) without
+ * a host synchronisation in the middle of the step (the Solver reads the flag word at its one sync point). */
+int bm_flag_unless_all_set(const unsigned char* mask, long n, int* flag, void* stream);
 int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores, float* probs,
                float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
                void* stream);

@@ -898,6 +898,29 @@ def test_rejected_batch_reuses_last_and_nonfinite_asserts():
     assert torch.isfinite(fresh.train_step(good))      # the flag does not stick
 
 
+def test_mask_assert_is_deferred_to_the_next_sync_point():
+    """bm/losses.py:110 `assert mask.all()`: stand-alone ClipLoss raises at once like the reference; under the Solver
+    the verdict travels in the device flag word and is raised at the next step's single synchronisation point."""
+    from brainmagick_amd.losses import ClipLoss
+    from brainmagick_amd.solver import Solver
+    est = torch.randn(4, 6, 30).cuda()
+    cand = torch.randn(4, 6, 30).cuda()
+    bad = torch.ones(4, 1, 30, dtype=torch.bool, device="cuda")
+    bad[2, 0, 7] = False
+    with pytest.raises(AssertionError):
+        ClipLoss().cuda()(est, cand, bad)
+    model, _ = _small_model()
+    solver = Solver(model)
+    good = synthetic.make_batch(4, 20, 48, 10, 3, seed=1)
+    masked = good.replace(features_mask=good.features_mask.clone())
+    masked.features_mask[1, 0, 5] = False
+    solver.train_step(good)
+    solver.train_step(masked)                      # flagged on the device, no sync in the middle of the step
+    with pytest.raises(AssertionError, match="mask"):
+        solver.train_step(good)
+    assert torch.isfinite(solver.train_step(good))  # the flag does not stick
+
+
 def test_deep_mel_shape_like_reference():
     """bm/test_model.py:53-68 (fake_batch features [2, 8, 128]): output keeps batch and time, n_out channels."""
     from brainmagick_amd.models import DeepMel
