@@ -615,6 +615,30 @@ def test_two_replicas_match_the_data_parallel_oracle(negatives):
             assert running_stat_close(v, oracles[0].sd[n], steps), n
 
 
+def test_bench_self_launches_on_two_gpus_when_visible():
+    """`python bench.py --gpus 2` outside a torchrun environment re-launches itself under torch.distributed.run, one
+    rank per GPU over the C-ABI RCCL communicator, whole-node negatives with the candidate gather prefetched; rank 0
+    prints ONE JSON line LAST on stdout (skipped on the 1-GPU test box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs")
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BM_FORCE_DISTRIBUTED"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--accuracy-steps", "0", "--no-exact", "--no-clip"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_world"] == 2 and line["config"]["negatives"] == "node"
+    assert line["config"]["global_batch"] == 512 and line["value"] > 0
+
+
 # Dimensions of the long-horizon parity runs (this test and bench.py's `retrieval_parity`): every contraction of the
 # step runs in the SAME kernels as the headline benchmark -- the wide f16x2 conv (T > 128, M >= 96), the wide f16x2
 # weight gradients (M a multiple of 256 / 320 within 25 %, Cn of 64) and the f16x2 score contraction (batch >= 128);
