@@ -149,7 +149,10 @@ def run_replicas(world: int, body: tp.Callable[[int], tp.Any]) -> tp.List[tp.Any
         try:
             if comm._gpu:
                 torch.cuda.set_device(0)
-            results[r] = body(r)
+            # backward on the CALLING thread: with the engine's shared per-device worker thread a collective inside a
+            # backward node (the adjoint of the learnable-candidate gather) would block the other replica's nodes
+            with torch.autograd.set_multithreading_enabled(False):
+                results[r] = body(r)
         except BaseException as exc:            # noqa: BLE001 -- reported by the caller
             errors[r] = exc
             comm.abort()

@@ -225,10 +225,11 @@ def test_paper_model_step_against_oracle(cfg_name, B, T):
             assert running_stat_close(v, oracle.sd[k], 2), k
 
 
-@pytest.mark.parametrize("cfg_name,B", [("cfg2", 256), ("cfg3", 256), ("cfg5", 64)])
+@pytest.mark.parametrize("cfg_name,B", [("cfg2", 256), ("cfg3", 256), ("cfg5", 64), ("cfg5", 256)])
 def test_full_size_step_against_oracle(cfg_name, B):
     """BASELINE.json configs[1] / configs[2] at their FULL size (batch 256, F = 120 / 1024) and the mixed
-    MEG/EEG config (273 sensors, 115 subjects, two layouts) at batch 64: loss, estimate and every
+    MEG/EEG config (273 sensors, 115 subjects, two layouts) at batch 64 (layer-by-layer front end: more (layout,
+    subject) pairs than segments) and at batch 256 (composed front end over 230 pairs): loss, estimate and every
     gradient of one training step against the CPU oracle (the oracle needs ~15 s per config on the GPU
     box's host cores).  Same tolerances as the reduced-size tests, except the 1-D parameters (biases,
     BatchNorm affine): their gradients are plain sums over B*T = 92 160 samples, where the fp32
@@ -613,6 +614,67 @@ def test_two_replicas_match_the_data_parallel_oracle(negatives):
             assert ok, (n, info)
         else:
             assert running_stat_close(v, oracles[0].sd[n], steps), n
+
+
+def test_two_replicas_with_learnable_candidates_match_joint_autograd():
+    """DeepMel feature model + whole-node negatives at world size 2 (loopback communicator, tests/loopback.py): the
+    candidates of both ranks are gathered with the autograd-aware all-gather (its backward reduce-scatters dCand to
+    the owner), so the feature model's gradient is that of the MEAN over ranks of the per-rank losses.  Oracle = torch
+    autograd on the CPU over both ranks jointly; compared: per-rank losses and the reduce-scattered gradient shards."""
+    from loopback import run_replicas
+    from brainmagick_amd import distrib
+    from brainmagick_amd.models import SimpleConv, DeepMel
+    from brainmagick_amd.solver import Solver
+    world, B = 2, 6
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=24, initial_linear=24, depth=4, merger_dropout=0.0)
+    C, T, Fd, S, hidden, out_ch = 20, 64, 12, 3, 32, 16
+    fm_kw = dict(n_hidden_channels=24, n_hidden_layers=4, n_out_channels=out_ch, kernel=3, stride=1,
+                 dilation_growth=2, dilation_period=5, batch_norm=True, activation_on_last=False,
+                 skip=True, glu_context=1, glu=2)
+
+    def build():
+        torch.manual_seed(2)
+        model = SimpleConv(in_channels={"meg": C}, out_channels=out_ch, hidden={"meg": hidden}, n_subjects=S, **cfg)
+        return model, DeepMel(n_in_channels=Fd, **fm_kw)
+
+    m0, f0 = build()
+    sd_m, sd_f = copy.deepcopy(m0.state_dict()), copy.deepcopy(f0.state_dict())
+    recordings = synthetic.make_layouts(1, [C], torch.Generator().manual_seed(4))
+    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=70 + r, recordings=recordings) for r in range(world)]
+
+    def body(r):
+        model, fmodel = build()
+        solver = Solver(model, feature_model=fmodel, negatives="node")
+        loss = float(solver.train_step(batches[r]))
+        opt = solver.optimizer
+        lo, hi = distrib.shard_bounds(opt.padded, world, r)
+        names = [("m", k) for k, _ in model.named_parameters()] + [("f", k) for k, _ in fmodel.named_parameters()]
+        return dict(loss=loss, shard=(lo, hi), grad_shard=opt.flat_grad[lo:hi].clone().cpu(), names=names,
+                    offsets=list(opt.offsets))
+
+    res = run_replicas(world, body)
+
+    om = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd_m.items()}
+    of = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd_f.items()}
+    ests, cands = [], []
+    for r in range(world):
+        sb = batches[r]
+        ests.append(O.simpleconv_forward(om, cfg, sb.meg, sb.positions(), sb.subject_index, hidden, out_ch,
+                                         training=True))
+        cands.append(O.deep_mel_forward(of, sb.features, 24, 4, out_ch, training=True))
+    allc = torch.cat(cands)
+    losses = [O.clip_loss(ests[r], torch.roll(allc, -r * B, 0)) for r in range(world)]
+    (sum(losses) / world).backward()
+    for r in range(world):
+        assert abs(res[r]["loss"] - float(losses[r])) < LOSS_TOL, (r, res[r]["loss"], float(losses[r]))
+    full = torch.zeros(max(res[0]["offsets"]) + 10 ** 6, dtype=torch.float64)
+    for (which, k), off in zip(res[0]["names"], res[0]["offsets"]):
+        g = (om if which == "m" else of)[k].grad
+        full[off:off + g.numel()] = g.reshape(-1).double()
+    for r in range(world):
+        lo, hi = res[r]["shard"]
+        assert rel_l2(res[r]["grad_shard"] / world, full[lo:hi]) < GRAD_TOL, (r, rel_l2(res[r]["grad_shard"] / world, full[lo:hi]))
 
 
 def test_bench_self_launches_on_two_gpus_when_visible():
