@@ -514,3 +514,45 @@ print("ADOPT_OK", dist.get_rank(), flush=True)
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ADOPT_OK {r}" in out, out
+
+
+def test_f16x2_split_bound_on_the_cpu():
+    """The arithmetic of the f16x2 contractions (power-of-two scale, two f16 planes, three products)
+    emulated with numpy: norm-wise fp32-class always; with ONE scale per tensor a channel d decades below the maximum
+    follows the documented 2^-37 * 10^d bound; with per-row scales every row is fp32-class.  (The GPU kernels are
+    held to the same numbers by tests/test_f16x2_gpu.py::test_per_channel_spread_*.)"""
+    import numpy as np
+
+    def scale_from_amax(a):
+        return 2.0 ** (14 - np.floor(np.log2(a)))
+
+    def split(x, s):
+        xs = (x * s).astype(np.float32)
+        hi = xs.astype(np.float16)
+        lo = (xs - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    rng = np.random.default_rng(0)
+    M, C, K = 48, 40, 2048
+    for decades in (0, 4, 6, 8):
+        sd = np.logspace(0, -decades, M)
+        dy = (rng.standard_normal((M, K)) * sd[:, None]).astype(np.float32)
+        x = rng.standard_normal((C, K)).astype(np.float32)
+        ref = dy.astype(np.float64) @ x.astype(np.float64).T
+        sx = scale_from_amax(np.abs(x).max())
+        xh, xl = split(x, sx)
+        # one scale per tensor
+        sa = scale_from_amax(np.abs(dy).max())
+        ah, al = split(dy, sa)
+        got = (ah @ xh.T + ah @ xl.T + al @ xh.T) / (sa * sx)
+        row = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 5e-7
+        assert (row <= np.maximum(2e-6, 2.0 ** -37 / sd)).all(), (decades, (row * sd).max())
+        if decades == 8:
+            assert row.max() > 1e-5          # the bound is not vacuous: far-down rows do lose accuracy
+        # one scale per row
+        sar = np.array([scale_from_amax(np.abs(r).max()) for r in dy])
+        ah, al = split(dy, sar[:, None])
+        got = (ah @ xh.T + ah @ xl.T + al @ xh.T) / (sar[:, None] * sx)
+        row = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert row.max() < 5e-7, (decades, row.max())
