@@ -984,6 +984,31 @@ def test_rejected_batch_reuses_last_and_nonfinite_asserts():
     assert torch.isfinite(fresh.train_step(good))      # the flag does not stick
 
 
+def test_prefetch_is_by_identity_and_can_be_abandoned():
+    """Solver.train_step(batch, next_batch=...) prepares the next batch ahead (device copy, max / finiteness pass, and
+    with whole-node negatives the candidate gather); the prepared state is used only if the SAME batch object comes
+    next, otherwise dropped -- losses equal those of plain stepping either way."""
+    from brainmagick_amd.solver import Solver
+    batches = [synthetic.make_batch(4, 20, 48, 10, 3, seed=30 + k) for k in range(4)]
+
+    def run(mode):
+        model, _ = _small_model(merger_dropout=0.0)
+        solver = Solver(model)
+        out = []
+        for k in range(3):
+            if mode == "plain":
+                out.append(float(solver.train_step(batches[k])))
+            elif mode == "ahead":
+                out.append(float(solver.train_step(batches[k], next_batch=batches[k + 1])))
+            else:                                   # announces one batch, trains on another
+                out.append(float(solver.train_step(batches[k], next_batch=batches[3])))
+        return out
+
+    plain = run("plain")
+    assert run("ahead") == plain
+    assert run("abandoned") == plain
+
+
 def test_mask_assert_is_deferred_to_the_next_sync_point():
     """bm/losses.py:110 `assert mask.all()`: stand-alone ClipLoss raises at once like the reference; under the Solver
     the verdict travels in the device flag word and is raised at the next step's single synchronisation point."""
