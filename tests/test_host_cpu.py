@@ -556,3 +556,18 @@ def test_f16x2_split_bound_on_the_cpu():
         got = (ah @ xh.T + ah @ xl.T + al @ xh.T) / (sar[:, None] * sx)
         row = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
         assert row.max() < 5e-7, (decades, row.max())
+
+
+def test_clip_candidate_blocks_cover_the_set_below_the_addressing_limit():
+    """ClipLoss walks candidate sets beyond 1 GB in row blocks (2 048 wav2vec2-sized candidates of 8 ranks = 3 GB):
+    the blocks tile the rows exactly, each slab stays below the kernels' 32-bit / staged-window limit, and the
+    per-rank sizes of the paper's configurations need a single block."""
+    from brainmagick_amd import functional as BF
+    for Bc, K in [(256, 120 * 360), (256, 1024 * 360), (2048, 120 * 360)]:
+        assert BF._candidate_blocks(Bc, K) == [(0, Bc)]
+    for Bc, K in [(2048, 1024 * 360), (4096, 1024 * 360), (1000, 1024 * 361), (3, 200_000_000)]:
+        blocks = BF._candidate_blocks(Bc, K)
+        assert len(blocks) > 1 and blocks[0][0] == 0
+        assert sum(n for _, n in blocks) == Bc
+        assert all(r0 == sum(n for _, n in blocks[:i]) for i, (r0, _) in enumerate(blocks))
+        assert all(n >= 1 and n * K * 4 < 0x40000000 or n == 1 for _, n in blocks)
