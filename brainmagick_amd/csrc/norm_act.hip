@@ -4,6 +4,7 @@
 // every kernel streams rows with 16-byte accesses when T % 4 == 0 (the 360-sample case) and falls
 // back to dword accesses otherwise (T = 343 / 361 ...).  Channel reductions are two-stage
 // (per-(channel, split) partials in a fixed order -> deterministic).
+#include <cstdlib>
 #include "bm_common.h"
 
 template <int VEC> struct Pack;
@@ -224,11 +225,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ partial, int bn_train, float* __restrict__ dy,
     double* __restrict__ dy_partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-    int C, int T, int act, float leak, BmAmaxDst amax_ws) {
+    int C, int T, int act, float leak, BmAmaxDst amax_ws, int reverse) {
     __shared__ double sh[4];
     __shared__ float amax_sh[4];
     float amx = 0.f;
-    const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+    // `reverse`: walk the batch splits in the opposite order of the reduce pass that has just streamed the same two
+    // tensors -- what that pass read last is what the memory-side cache still holds (236 of its 256 MB)
+    const int c = blockIdx.x, nsplit = gridDim.y, split = reverse ? nsplit - 1 - (int)blockIdx.y : (int)blockIdx.y;
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
     const float sc = scale ? scale[c] : 1.f, shf = scale ? shift[c] : 0.f;
@@ -288,6 +291,16 @@ __global__ void finalize_channel_sums_kernel(const double* __restrict__ partial,
 
 extern "C" int bm_bwd_nsplit(int B) { return B >= 64 ? 8 : (B >= 8 ? 4 : 1); }
 
+// BM_BN_APPLY_REVERSE=0: the apply pass walks the batch in the same order as the reduce pass (A/B switch)
+static int bn_apply_reverse() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("BM_BN_APPLY_REVERSE");
+        on = !(e && e[0] == '0');
+    }
+    return on;
+}
+
 // workspace: doubles, (2*C*nsplit) for the reduce partials + (C*nsplit) for the dy sums.
 extern "C" long bm_act_bn_bwd_workspace_bytes(int B, int C) {
     return (long)3 * C * bm_bwd_nsplit(B) * sizeof(double);
@@ -319,14 +332,14 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
-                           amax_dst);
+                           amax_dst, bn_apply_reverse());
     } else {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
-                           amax_dst);
+                           amax_dst, bn_apply_reverse());
     }
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dy_partial,
