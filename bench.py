@@ -252,6 +252,8 @@ def clip_roofline(dev, mode, reps=20):
         cand = torch.empty(Bc, F, T, device=dev)
         for r0 in range(0, Bc, 256):
             cand[r0:r0 + 256] = torch.randn(256, F, T, generator=g).to(dev)
+        if os.environ.get("BM_BENCH_ZERO_OPERANDS"):      # DVFS probe: same launches, operands that do not toggle
+            est.zero_(), cand.zero_()
         inv = hip_ops.clip_inv_norms(cand)
         n_rep = reps if Bc == 256 else max(3, reps // 4)
         for _ in range(2):

@@ -10,8 +10,10 @@
 //
 // ONE workgroup of four wavefronts per CU (one per SIMD); a wavefront owns (32 MW) rows x (32 columns x NS
 // "slots") as MW x NS MFMA accumulators; the slots are the three taps of 64 X rows (KS = 3, NS = 3) or NS blocks
-// of 64 X rows (KS = 1).  Tiles: <3,5,3> and <1,5,3> 320 x 192 (weight gradients), <1,4,2> 256 x 128 (ClipLoss
-// scores at batch 256: two column tiles x 128 K-splits fill the chip with 33 MB of partial tiles).
+// of 64 X rows (KS = 1).  Tiles: <3,5,3> and <1,5,3> 320 x 192 (weight gradients), <1,4,2> 256 x 128, and
+// <1,4,4,TS> 256 x 256 with a TRANSPOSED partial tile (ClipLoss scores, bm_clip_scores_h2: A = candidates, X =
+// estimates, part[split][estimate][candidate] -- a lane's four consecutive accumulator rows are four consecutive
+// candidates of one estimate, stored as one 16-byte write instead of four scattered dwords).
 //
 // Stage = 32 samples = two MFMA k-steps.  A stage's operands are fetched as FULL 128-byte lines: eight lanes per
 // row (4 samples = 16 bytes each), 32 rows per wave-load pass, 2 MW + 2 NS passes per thread.  (With 16-sample
@@ -120,6 +122,10 @@ __device__ __forceinline__ void hg_barrier(f16x8 (&ah)[MW], f16x8 (&bh)[NS]) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier"
                      : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(ah[4]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
                      :: "memory");
+    else if constexpr (MW == 4 && NS == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier"
+                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3])
+                     :: "memory");
     else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier"
                      : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bh[0]), "+v"(bh[1])
@@ -163,9 +169,12 @@ extern "C" int bm_debug_trace_read(long long* out) {
 // tensor's maximum then keeps its 22 bits.  Needs T % 4 == 0: a 4-sample piece is then entirely
 // inside or outside a row, pieces outside are fetched at an out-of-range offset (zeros), and A needs no per-value
 // edge scales.
-template <int KS, int MW, int NS, bool RS = false>
+// TS ("transposed store"): part[split][c][m] (row length M) instead of part[split][m][c]; needs M % 4 == 0.
+template <int KS, int MW, int NS, bool RS = false, bool TS = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
-    static_assert((MW == 5 && NS == 3) || (MW == 4 && NS == 2), "tile variants: 320 x 192, 256 x 128");
+    static_assert((MW == 5 && NS == 3) || (MW == 4 && NS == 2) || (MW == 4 && NS == 4),
+                  "tile variants: 320 x 192, 256 x 128, 256 x 256");
+    static_assert(!TS || (KS == 1 && !RS), "the transposed partial tile is the score contraction's");
     static_assert(KS == 1 || NS == 3, "3 taps use the 3 slots");
     constexpr int NA = 2 * MW;                        // A pieces per thread and stage (32 rows per pass)
     constexpr int NX = 2 * NS;                        // X pieces (slot j, 32-row half u)
@@ -467,6 +476,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
         }
         __syncthreads();
     }
+    if constexpr (TS) {
+        // element r of a lane: row (r & 3) + 8 (r >> 2) + 4 h of the block -- rows 4 q' .. 4 q' + 3 are r = 4 q .. 4 q + 3
+        const float f = sa_inv * sx_inv;
+        float* dstT = a.part + (long)split * a.Cn * a.M;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int c = c0 + 64 * j + wc * 32 + nl;
+            if (c < a.Cn) {
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = m0 + wm * (MW * 32) + mt * 32 + 8 * q + 4 * h;
+                        if (m < a.M)        // M % 4 == 0: the four rows are inside or outside together
+                            *reinterpret_cast<float4*>(dstT + (long)c * a.M + m) =
+                                float4{acc[mt][j][4 * q] * f, acc[mt][j][4 * q + 1] * f, acc[mt][j][4 * q + 2] * f,
+                                       acc[mt][j][4 * q + 3] * f};
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt) {
 #pragma unroll
@@ -538,13 +569,13 @@ extern "C" int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T)
     return (int)want;
 }
 
-template <int KS, int MW, int NS, bool RS = false>
+template <int KS, int MW, int NS, bool RS = false, bool TS = false>
 static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     constexpr int PLANE = 4 * (64 * MW + 2) + NS * 4 * HG_XQ;
     const size_t lds = (size_t)2 * 2 * PLANE * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_h2w_kernel<KS, MW, NS, RS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_h2w_kernel<KS, MW, NS, RS, TS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt_h2w: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -552,7 +583,7 @@ static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     g.tiles_m = cdiv(g.M, 64 * MW);
     g.tiles_c = cdiv(g.Cn, KS == 3 ? 64 : 64 * NS);
     const long nblocks = (long)g.tiles_m * g.tiles_c * g.nsplit;
-    hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS, RS>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS, RS, TS>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
     return bm_check_launch("gemm_nt_h2w");
 }
 
@@ -604,4 +635,52 @@ extern "C" int bm_gemm_nt_h2_rows(const float* a, long a_sstride, long a_rstride
                                   int nsplit, void* stream) {
     return gemm_nt_h2_impl(a, a_sstride, a_rstride, a_amax, a_row_amax, x, x_sstride, x_rstride, x_amax, part, S, M, Cn,
                            T, KS, dil, nsplit, stream);
+}
+
+// ---- ClipLoss score contraction (bm/losses.py:94, the einsum "bct,oct->bo" before the candidate norms) ----
+// part[split][b][o] = sum over split `split` of the K axis of est[b][k] * cand[o][k], est [B][K], cand [Bc][K] dense.
+// 256 x 256 tiles with the CANDIDATES as the row operand and the tile stored transposed (kernel <1,4,4,TS>).
+// column tile of the estimates: 256 (kernel <1,4,4>) when that still leaves a workgroup >= 16 stages of K, else 128
+// (<1,4,2>: twice the workgroups per split, half the partial-tile bytes -- the F = 120 shapes, whose K is short)
+static int clip_scores_wide(int B, int Bc, long K) {
+    const long tiles = (long)cdiv(Bc, 256) * cdiv(B, 256);
+    const long chunks = (K + HG_K - 1) / HG_K;
+    long splits = 256 / tiles;
+    if (splits < 1) splits = 1;
+    return chunks / splits >= 16;
+}
+
+extern "C" int bm_clip_scores_h2_covers(int B, int Bc, long K) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("BM_CLIP_SCORES_KERNEL");      // BM_CLIP_SCORES_KERNEL=0: the generic bm_gemm_nt_h2 tiles (A/B switch)
+        on = !(e && e[0] == '0');
+    }
+    if (!on || B <= 0 || Bc <= 0 || Bc % 4 != 0 || K < 16 * HG_K || K >= 0x7fffffffL) return 0;
+    if (((long)(Bc - 1) * K + K) * 4 >= 0x7f000000L || ((long)(B - 1) * K + K) * 4 >= 0x7f000000L) return 0;
+    // padded rows / columns are wasted MFMA work
+    const int bc = clip_scores_wide(B, Bc, K) ? 256 : 128;
+    return (long)cdiv(Bc, 256) * 256 * cdiv(B, bc) * bc * 2 <= (long)B * Bc * 3;
+}
+
+extern "C" int bm_clip_scores_h2_suggest_splits(int B, int Bc, long K) {
+    const int bc = clip_scores_wide(B, Bc, K) ? 256 : 128;
+    const int tiles = cdiv(Bc, 256) * cdiv(B, bc);
+    const long chunks = (K + HG_K - 1) / HG_K;
+    long want = 256 / tiles;
+    if (want > chunks / 4) want = chunks / 4;
+    return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int bm_clip_scores_h2(const float* est, const float* est_amax, const float* cand, const float* cand_amax,
+                                 float* part, int B, int Bc, long K, int nsplit, void* stream) {
+    BM_REQUIRE(est && cand && part && est_amax && cand_amax, "clip_scores_h2: null pointer");
+    BM_REQUIRE(nsplit > 0, "clip_scores_h2: bad split count");
+    BM_REQUIRE(bm_clip_scores_h2_covers(B, Bc, K), "clip_scores_h2: shape not covered (B=%d Bc=%d K=%ld)", B, Bc, K);
+    GemmNTArgsH g;
+    g.a = cand; g.a_sstride = 0; g.a_rstride = K; g.a_amax = cand_amax; g.a_row_amax = nullptr;
+    g.x = est; g.x_sstride = 0; g.x_rstride = K; g.x_amax = est_amax;
+    g.part = part; g.S = 1; g.M = Bc; g.Cn = B; g.T = (int)K; g.dil = 1; g.nsplit = nsplit;
+    if (clip_scores_wide(B, Bc, K)) return launch_gemm_nt_h2w<1, 4, 4, false, true>(g, (hipStream_t)stream);
+    return launch_gemm_nt_h2w<1, 4, 2, false, true>(g, (hipStream_t)stream);
 }

@@ -568,11 +568,23 @@ def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
     mode = "f32" if _compute_dtype == "bf16" else _compute_dtype
     if mode == "f16x2" and not lib().bm_gemm_nt_h2_covers(M, Cn, 1, S, T, 1, 1, 0):
         mode = "f32x3"
+    # the score contraction proper (dense [M][T] x [Cn][T]): 256 x 256 tiles, transposed vector stores
+    scores_kernel = mode == "f16x2" and S == 1 and tuple(a_strides) == (0, T) and tuple(x_strides) == (0, T) and \
+        bool(lib().bm_clip_scores_h2_covers(M, Cn, T))
     if nsplit is None:
-        nsplit = lib().bm_gemm_nt_h2_suggest_splits(M, Cn, 1, S, T) if mode == "f16x2" else \
-            lib().bm_clip_suggest_splits(M, Cn, S, T)
+        if scores_kernel:
+            nsplit = lib().bm_clip_scores_h2_suggest_splits(M, Cn, T)
+        else:
+            nsplit = lib().bm_gemm_nt_h2_suggest_splits(M, Cn, 1, S, T) if mode == "f16x2" else \
+                lib().bm_clip_suggest_splits(M, Cn, S, T)
     part = torch.empty(nsplit, M, Cn, device=a.device, dtype=torch.float32)
-    if mode == "f16x2":
+    if scores_kernel:
+        a_amax, x_amax = amax(a), amax(x)
+
+        def launch():
+            check(lib().bm_clip_scores_h2(_p(a), _p(a_amax), _p(x), _p(x_amax), _p(part), M, Cn, T, nsplit, _stream()),
+                  "bm_clip_scores_h2")
+    elif mode == "f16x2":
         a_amax, x_amax = amax(a), amax(x)
 
         def launch():

@@ -151,6 +151,16 @@ int bm_gemm_nt_h2_rows(const float* a, long a_sstride, long a_rstride, const flo
                        const float* x, long x_sstride, long x_rstride, const float* x_amax, float* part, int S,
                        int M, int Cn, int T, int KS, int dil, int nsplit, void* stream);
 
+/* ClipLoss score contraction in compute mode "f16x2" (bm/losses.py:94, torch.einsum("bct,oct,o->bo") before the
+ * candidate norms): part[split][b][o] = sum over the split's share of k of est[b][k] * cand[o][k]; est [B][K] and
+ * cand [Bc][K] dense fp32, K = F * T; est_amax / cand_amax as for bm_gemm_nt_h2.  256 candidates x 256 (long K) or 128
+ * (short K) estimates per tile, the partial tiles written with 16-byte stores; folded by bm_clip_ce.  Only shapes bm_clip_scores_h2_covers() accepts (Bc % 4 == 0,
+ * operands below 2 GB, at most half of a tile padded); otherwise bm_gemm_nt_h2 with M = B, Cn = Bc computes the same. */
+int bm_clip_scores_h2_covers(int B, int Bc, long K);
+int bm_clip_scores_h2_suggest_splits(int B, int Bc, long K);
+int bm_clip_scores_h2(const float* est, const float* est_amax, const float* cand, const float* cand_amax, float* part,
+                      int B, int Bc, long K, int nsplit, void* stream);
+
 /* ---- time-contraction GEMM, fp32 MFMA, split-K (gemm_nt.hip) ----
  * part[g,split][m][c*KS+j] = sum_{s in group g} sum_t A[s][m][t] * X[s][c][t + (j-KS/2)*dil].
  * Replaces aten::convolution_backward (weight part), the weight-grad einsums of SubjectLayers /

@@ -13,10 +13,14 @@ from brainmagick_amd import hip_ops as H  # noqa: E402
 B, T = 256, 360
 SEG = ["wait loads", "k-step 0 + split", "fetch issue", "k-step 1 (30 MFMA)", "barrier", "early frags + 15 MFMA"]
 g = torch.Generator().manual_seed(0)
-for Cin, M, KS, dil in [(320, 320, 3, 2), (320, 640, 1, 1), (256, 256, 0, 1)]:
+import os
+SHAPES = [(320, 320, 3, 2), (320, 640, 1, 1), (256, 256, 0, 120), (256, 256, 0, 1024)]
+if os.environ.get("TRACE_ONLY_CLIP"):
+    SHAPES = SHAPES[2:]
+for Cin, M, KS, dil in SHAPES:
     brainmagick_amd.set_compute_dtype("f16x2")
-    if KS == 0:                 # the ClipLoss score contraction at F = 120: one segment of K = F * T samples
-        K = 120 * T
+    if KS == 0:                 # the ClipLoss score contraction at F = dil: one segment of K = F * T samples
+        K = dil * T
         est = torch.randn(256, K, generator=g).cuda()
         cand = torch.randn(256, K, generator=g).cuda()
         for _ in range(3):

@@ -314,6 +314,39 @@ def test_clip(h2_mode, H, B, Bc, Fd, T):
     TK.test_clip_kernels(H, B, Bc, Fd, T)
 
 
+@pytest.mark.parametrize("B,Bc,K", [(256, 256, 43200), (256, 256, 368640), (250, 252, 4999), (256, 512, 1537),
+                                    (180, 256, 777), (100, 256, 3000), (256, 2048, 20000)])
+def test_score_contraction_256_tiles(h2_mode, H, B, Bc, K):
+    """bm_clip_scores_h2 (256 x 256 tiles, candidates as the row operand, transposed 16-byte stores of the partial
+    tiles): rows / columns past the operands, a ragged last chunk, K not a multiple of 4 (rows only 4-byte aligned),
+    several row tiles -- against fp64, and against the generic 256 x 128 kernel it replaces."""
+    from brainmagick_amd._lib import lib
+    assert lib().bm_clip_scores_h2_covers(B, Bc, K)
+    g = _gen(B + Bc + K)
+    est = torch.randn(B, K, generator=g)
+    cand = torch.randn(Bc, K, generator=g) * torch.logspace(0, -3, Bc)[:, None]     # candidates of different norm
+    eg, cg = est.cuda(), cand.cuda()
+    part = H.gemm_nt_partials(eg, cg, 1, B, Bc, K, (0, K), (0, K))
+    assert part.shape[1:] == (B, Bc)
+    got = part.sum(0).double().cpu()
+    ref = est.double() @ cand.double().t()
+    # norm-wise per candidate (column): every candidate keeps fp32-class accuracy relative to its own scores' scale...
+    col_err = (got - ref).norm(dim=0) / ref.norm(dim=0)
+    # ... down to the f16x2 bound of a candidate 2^-10 below the tensor maximum (DESIGN.md section 2)
+    assert float(col_err.max()) < 2e-5, float(col_err.max())
+    assert float(col_err[: Bc // 3].max()) < 2e-6, float(col_err[: Bc // 3].max())
+    # the generic tiles agree (different split counts: fp32 summation order differs)
+    if lib().bm_gemm_nt_h2_covers(B, Bc, 1, 1, K, 1, 1, 0):
+        nsplit = lib().bm_gemm_nt_h2_suggest_splits(B, Bc, 1, 1, K)
+        a_amax, x_amax = H.amax(eg), H.amax(cg)
+        part2 = torch.empty(nsplit, B, Bc, device="cuda")
+        from brainmagick_amd.hip_ops import check, _p, _stream
+        check(lib().bm_gemm_nt_h2(_p(eg), 0, K, _p(a_amax), _p(cg), 0, K, _p(x_amax), _p(part2), 1, B, Bc, K, 1, 1,
+                                  nsplit, _stream()), "bm_gemm_nt_h2")
+        got2 = part2.sum(0).double().cpu()
+        assert float((got - got2).norm() / ref.norm()) < 2e-6
+
+
 def test_producers_publish_their_own_maximum(h2_mode, H):
     """The elementwise kernels and the conv epilogue publish max|output| themselves (per-workgroup partial maxima);
     the consuming contraction then needs no pass over the tensor."""
