@@ -23,9 +23,11 @@ the buffers.  ``torch.distributed`` is used for the CPU tests ("gloo") and as an
 
 Everything degrades to a no-op at world_size 1.
 """
+import contextlib
 import ctypes
 import datetime
 import os
+import sys
 import typing as tp
 
 import torch
@@ -126,6 +128,30 @@ def _all_ranks_ok(store, key: str, rank: int, world: int, ok: bool) -> bool:
     return all(bytes(store.get(f"{key}/{r}")) == b"1" for r in range(world))
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """librccl prints a version banner to the C-level stdout when the first communicator comes up.  A tool that
+    prints a machine-readable line on stdout (bench.py) must not have library chatter in front of it: while the
+    communicator is created, file descriptor 1 points at stderr."""
+    try:
+        sys.stdout.flush()
+        libc = ctypes.CDLL(None)
+        libc.fflush(None)
+        saved = os.dup(1)
+    except Exception:                       # no usable fd 1 (embedded interpreter): nothing to protect
+        yield
+        return
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        try:
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+
+
 class RcclUnavailable(RuntimeError):
     """RCCL through the C-ABI cannot be used on at least one rank (agreed through the rendezvous store)."""
 
@@ -169,7 +195,8 @@ class _RcclComm:
         # phase 2: the communicator itself; the outcome is agreed again so that a rank whose init failed does
         # not leave the others with a communicator nobody else joins
         handle = ctypes.c_void_p()
-        rc = self._lib.bm_comm_init(uid, self.world, self.rank, self.device, ctypes.byref(handle))
+        with _c_stdout_to_stderr():
+            rc = self._lib.bm_comm_init(uid, self.world, self.rank, self.device, ctypes.byref(handle))
         ok = rc == 0
         msg = "" if ok else (self._lib.bm_last_error() or b"").decode()
         if self._store is not None:

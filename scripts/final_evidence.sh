@@ -10,13 +10,13 @@ SIDE="--no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip"
 timeout 300 python bench.py --workload cfg3 $SIDE > gpurun_out/${TAG}_bench_cfg3.json 2>/dev/null; echo "cfg3 rc=$?"
 timeout 300 python bench.py --workload cfg5 $SIDE > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null; echo "cfg5 rc=$?"
 timeout 300 python bench.py --steps 200 --warmup 5 $SIDE > gpurun_out/${TAG}_bench_sustained_200steps.json 2>/dev/null; echo "sustained rc=$?"
-BM_FORCE_DISTRIBUTED=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29631 timeout 300 \
-  python bench.py --negatives node $SIDE > gpurun_out/${TAG}_bench_forced_rccl_world1_node.json 2>/dev/null; echo "forced rccl rc=$?"
+BM_FORCE_DISTRIBUTED=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$((29000 + RANDOM % 900)) timeout 300 \
+  python bench.py --negatives node $SIDE > gpurun_out/${TAG}_bench_forced_rccl_world1_node.json 2> gpurun_out/${TAG}_bench_forced.err; echo "forced rccl rc=$?"
 for f in cfg3 cfg5 sustained_200steps forced_rccl_world1_node; do
   python - gpurun_out/${TAG}_bench_$f.json <<'PY'
 import json, sys
 try:
-    d = json.load(open(sys.argv[1]))
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     print(sys.argv[1].split("/")[-1], "ms/step", round(d["ms_per_step"], 3), "seg/s", round(d["value"]), d["config"].get("comm"), d["config"].get("negatives"), d["config"].get("candidate_gather"))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)

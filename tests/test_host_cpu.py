@@ -571,3 +571,25 @@ def test_clip_candidate_blocks_cover_the_set_below_the_addressing_limit():
         assert sum(n for _, n in blocks) == Bc
         assert all(r0 == sum(n for _, n in blocks[:i]) for i, (r0, _) in enumerate(blocks))
         assert all(n >= 1 and n * K * 4 < 0x40000000 or n == 1 for _, n in blocks)
+
+
+def test_c_level_stdout_is_parked_on_stderr_while_a_communicator_comes_up():
+    """librccl prints a version banner with printf when the first communicator is created; bench.py's contract is
+    ONE JSON line on stdout.  `distrib._c_stdout_to_stderr` (wrapped around `bm_comm_init`) points fd 1 at stderr
+    for the duration, C buffers flushed on both sides."""
+    import subprocess
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from brainmagick_amd import distrib\n"
+        "libc = ctypes.CDLL(None)\n"
+        "print('before')\n"
+        "with distrib._c_stdout_to_stderr():\n"
+        "    libc.printf(b'BANNER\\n')\n"
+        "libc.printf(b'after-c\\n')\n"
+        "libc.fflush(None)\n"
+        "print('after')\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.split() == ["before", "after-c", "after"], p.stdout
+    assert "BANNER" in p.stderr

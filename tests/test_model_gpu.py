@@ -701,6 +701,30 @@ def test_bench_self_launches_on_two_gpus_when_visible():
     assert line["config"]["global_batch"] == 512 and line["value"] > 0
 
 
+def test_bench_under_a_launcher_prints_one_json_line_and_nothing_else():
+    """The driver's contract for N > 1: started with RANK / WORLD_SIZE / MASTER_* in the environment, bench.py
+    brings the C-ABI RCCL communicator up (here at world size 1: the same code path, `BM_FORCE_DISTRIBUTED`) and
+    rank 0 prints exactly ONE line on stdout -- librccl's version banner goes to stderr."""
+    import json
+    import os
+    import random
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BM_FORCE_DISTRIBUTED="1", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(random.randint(20000, 28000)))
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--negatives", "node", "--no-cpu-baseline", "--accuracy-steps", "0", "--no-exact",
+                          "--no-clip"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines[:5]
+    line = json.loads(lines[0])
+    assert line["config"]["comm"] == "rccl/c-abi" and line["config"]["rccl_world"] == 1
+    assert line["config"]["negatives"] == "node" and line["value"] > 0
+
+
 # Dimensions of the long-horizon parity runs (this test and bench.py's `retrieval_parity`): every contraction of the
 # step runs in the SAME kernels as the headline benchmark -- the wide f16x2 conv (T > 128, M >= 96), the wide f16x2
 # weight gradients (M a multiple of 256 / 320 within 25 %, Cn of 64) and the f16x2 score contraction (batch >= 128);
