@@ -156,6 +156,52 @@ __device__ __forceinline__ float h2_general_blocks(const ConvNNArgs& a, f32x16 (
     return amx;
 }
 
+// BatchNorm statistics of the tile (training-mode conv + BN layers, bm/models/common.py:119): per output row, sum and
+// sum of squares of y_pre = acc + bias over this wavefront's 96 columns, written as partial row (tile, wavefront
+// column) of `stats` [B * ntiles_n * 2][M][2] -- bm_bn_finalize adds the partials in double.  Saves the
+// channel_stats pass over the 118 MB output.  Per row block: the lane's 3 column blocks are summed in registers,
+// then a halving butterfly over the 32 lanes of a half-wavefront (16 + 8 + 4 + 2 + 1 + 1 exchanges for 2 x 16
+// values instead of 5 x 32) leaves row q = 8 b4 + 4 b3 + 2 b2 + b1 (bk = bit k of the lane) in each lane.
+template <int MW>
+__device__ __forceinline__ void h2_tile_stats(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* epl /* lane's bias rows */,
+                                              float* stats_tile /* + (tile * 2 + wn) * M * 2 */, int row0 /* first row of the lane's blocks */,
+                                              int col0, int lane) {
+    const bool c0ok = col0 < a.T, c1ok = col0 + 32 < a.T, c2ok = col0 + 64 < a.T;
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    h2_static_for<MW>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mc)::value;
+        float s1[16], s2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bias = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+            const float v0 = c0ok ? acc[mt][0][r] + bias : 0.f;
+            const float v1 = c1ok ? acc[mt][1][r] + bias : 0.f;
+            const float v2 = c2ok ? acc[mt][2][r] + bias : 0.f;
+            s1[r] = (v0 + v1) + v2;
+            s2[r] = fmaf(v0, v0, fmaf(v1, v1, v2 * v2));
+        }
+#define H2_FOLD(N_, BIT_, MASK_)                                                                  \
+        _Pragma("unroll") for (int i = 0; i < N_; ++i) {                                          \
+            const float k1 = BIT_ ? s1[i + N_] : s1[i], g1 = BIT_ ? s1[i] : s1[i + N_];            \
+            const float k2 = BIT_ ? s2[i + N_] : s2[i], g2 = BIT_ ? s2[i] : s2[i + N_];            \
+            s1[i] = k1 + __shfl_xor(g1, MASK_);                                                   \
+            s2[i] = k2 + __shfl_xor(g2, MASK_);                                                   \
+        }
+        H2_FOLD(8, b4, 16)
+        H2_FOLD(4, b3, 8)
+        H2_FOLD(2, b2, 4)
+        H2_FOLD(1, b1, 2)
+#undef H2_FOLD
+        s1[0] += __shfl_xor(s1[0], 1);
+        s2[0] += __shfl_xor(s2[0], 1);
+        // element index q of the lane's 16 -> row (q & 3) + 8 (q >> 2) of the block (C/D layout)
+        const int q = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+        const int row = row0 + mt * 32 + (q & 3) + 8 * (q >> 2);
+        if (!(lane & 1) && row < a.M)
+            *reinterpret_cast<float2*>(stats_tile + (long)row * 2) = float2{s1[0], s2[0]};
+    });
+}
+
 template <int N, int MW>
 __device__ __forceinline__ void h2_barrier(f16x8 (&ah)[MW], f16x8 (&bh)[3]) {
     if constexpr (MW == 5)
@@ -462,6 +508,10 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     // addresses are wave-uniform bases + one per-lane offset + an immediate per column block, the row biases are
     // read once: ~3 VALU issue slots per stored element instead of ~10.  Tiles that straddle M (270-channel
     // layers in 320-row tiles) take the same path with a row predicate.
+    if (a.stats)            // training-mode BatchNorm layers: the host allows it only with y_pre alone (simple path)
+        h2_tile_stats<MW>(a, acc, ep + wm * (MW * 32) + 4 * h,
+                          a.stats + ((long)((b * a.ntiles_n + ntile) * 2 + wn) * a.M) * 2, m0 + wm * (MW * 32) + 4 * h,
+                          n0 + wn * (NW * 32) + nl, lane);
     const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE;
     if (simple) {
         H2Simple<MW> e;
@@ -537,6 +587,9 @@ extern "C" int bm_conv_h2_covers(int Cin, int M, int T, int KS, int dil) {
     // padded rows are wasted MFMA work: leave tiny layers (tests, F = 16 heads) to the narrow kernels
     return (long)bm_conv_h2_mpad(M) * 2 <= (long)M * 3 || M >= 96;
 }
+
+// rows of the `stats` buffer of bm_conv1d_nn_h2: one per (segment, column tile, wavefront column)
+extern "C" int bm_conv_h2_stats_tiles(int B, int T) { return B * cdiv(T, HBN) * 2; }
 
 // bytes of the packed buffer: f16 planes [G][chunk32][KS][2][4][Mpad][8] + fp32 inverse row scales [G][Mpad]
 extern "C" long bm_packed_weight_bytes_h2(int G, int M, int Cin, int KS) {
@@ -790,7 +843,8 @@ extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_am
                                int G, float* y_amax_out, float* amax_ws, void* stream) {
     BM_REQUIRE(x && wpacked && x_amax, "conv1d_nn_h2: null x / w / x_amax");
     BM_REQUIRE(y_pre || y_out, "conv1d_nn_h2: no output");
-    BM_REQUIRE(!stats, "conv1d_nn_h2: per-tile statistics are not produced by this kernel");
+    BM_REQUIRE(!stats || (y_pre && !y_out && !ep_scale && act == BM_ACT_NONE && !res),
+               "conv1d_nn_h2: per-tile statistics come with y_pre alone (the training-mode BatchNorm layers)");
     BM_REQUIRE(B >= 0 && Cin > 0 && M > 0 && T > 0 && dil >= 1 && G >= 1, "conv1d_nn_h2: bad dims");
     BM_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), "conv1d_nn_h2: scale/shift must come together");
     BM_REQUIRE(bm_conv_h2_covers(Cin, M, T, KS, dil), "conv1d_nn_h2: shape not covered (Cin=%d M=%d T=%d KS=%d dil=%d)",
@@ -799,7 +853,7 @@ extern "C" int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_am
     ConvNNArgs& a = args.c;
     a.x = x; a.x_bstride = x_bstride; a.wp = (const float*)wpacked; a.widx = widx; a.bias = bias; a.bias_gstride = bias_gstride;
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
-    a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = nullptr;
+    a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = stats;
     a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;
     const int mw = bm_conv_h2_mw_for(M);
     a.Mpad = bm_conv_h2_mpad(M);

@@ -15,6 +15,8 @@ import os
 # A/B switch (measurement only): BatchNorm partial statistics from the conv epilogue instead of the
 # separate streaming pass.
 _STATS_IN_EPILOGUE = os.environ.get("BM_STATS_IN_EPILOGUE", "0") == "1"
+# the wide f16x2 conv produces the BatchNorm partial sums in its epilogue (A/B switch: "0" = a channel_stats pass)
+_STATS_IN_EPILOGUE_H2 = os.environ.get("BM_STATS_IN_EPILOGUE_H2", "1") == "1"
 
 ACT_CODES = {"none": H.ACT_NONE, "gelu": H.ACT_GELU, "relu": H.ACT_RELU, "leaky": H.ACT_LEAKY}
 
@@ -99,8 +101,9 @@ class ConvBNActFn(torch.autograd.Function):
     """One ConvSequence layer: Conv1d -> BatchNorm1d -> activation [-> + input] as fused HIP
     kernels (bm/models/common.py:113-119 + :146-147).
 
-    train: conv_nn -> channel_stats (one streaming pass) -> bn_finalize (also updates the running
-    statistics like torch) -> affine_act_res.  eval: ONE conv_nn launch with the affine,
+    train: conv_nn (the wide f16x2 kernel adds the per-tile sums / sums of squares in its epilogue; the other
+    kernels are followed by a channel_stats streaming pass) -> bn_finalize (also updates the running statistics
+    like torch) -> affine_act_res.  eval: ONE conv_nn launch with the affine,
     activation and residual folded in its epilogue."""
 
     @staticmethod
@@ -114,7 +117,7 @@ class ConvBNActFn(torch.autograd.Function):
         res = x if residual else None
         needs_grad = x.requires_grad or weight.requires_grad
         if training:
-            if _STATS_IN_EPILOGUE:
+            if _STATS_IN_EPILOGUE or (_STATS_IN_EPILOGUE_H2 and getattr(wp, "_bm_mode", "") == "f16x2"):
                 pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True,
                                           want_out=False, want_stats=True)
             else:

@@ -384,8 +384,8 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
         y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
     stats = None
     if want_stats:
-        stats = torch.empty(lib().bm_conv_stats_tiles(B, T), M, 2, device=x.device,
-                            dtype=torch.float32)
+        ntiles = lib().bm_conv_h2_stats_tiles(B, T) if mode == "f16x2" else lib().bm_conv_stats_tiles(B, T)
+        stats = torch.empty(ntiles, M, 2, device=x.device, dtype=torch.float32)
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))

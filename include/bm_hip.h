@@ -131,6 +131,10 @@ int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
 /* Same pass, plus the reference's finiteness assert (bm/solver.py:258-260): *nonfinite_flag (device int, nullable)
  * is set to 1 when x holds an inf or a nan. */
 int bm_amax_checked(const float* x, long n, float* out, float* amax_ws, int* nonfinite_flag, void* stream);
+/* `stats` (nullable; only together with y_pre alone, no affine / activation / residual: the training-mode BatchNorm
+ * layers): [bm_conv_h2_stats_tiles(B, T)][M][2] per-(segment, column tile, wavefront column) partial sums and sums
+ * of squares of y_pre, every row written; input of bm_bn_finalize with ntiles = bm_conv_h2_stats_tiles(B, T). */
+int bm_conv_h2_stats_tiles(int B, int T);
 int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked, const int* widx,
                     const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B, int Cin,

@@ -347,6 +347,36 @@ def test_score_contraction_256_tiles(h2_mode, H, B, Bc, K):
         assert float((got - got2).norm() / ref.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("Cin,M,KS,dil,T,B", [(320, 320, 3, 2, 360, 3), (270, 320, 3, 1, 361, 2), (320, 270, 3, 4, 343, 2),
+                                               (64, 640, 3, 16, 193, 2), (320, 320, 1, 1, 360, 2)])
+def test_conv_epilogue_batchnorm_statistics(h2_mode, H, Cin, M, KS, dil, T, B):
+    """The wide conv's epilogue writes the per-(tile, wavefront column) sums and sums of squares of y_pre that
+    BatchNorm needs (every row of the stats buffer, also for tiles that straddle M or T); folded over the tiles
+    they equal the sums of the stored output, and bn_finalize on them equals bn_finalize on a channel_stats pass."""
+    g = _gen(Cin + M + T)
+    x = torch.randn(B, Cin, T, generator=g).cuda()
+    w = (torch.randn(M, Cin, KS, generator=g) / (Cin * KS) ** 0.5).cuda()
+    bias = (torch.randn(M, generator=g) * 3).cuda()           # a mean far from zero in some channels
+    wp = H.pack_conv_fwd(w, (T, dil))
+    assert wp._bm_mode == "f16x2"
+    pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False, want_stats=True)
+    pre2, _, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False)
+    assert torch.equal(pre, pre2)                             # the statistics do not disturb the output
+    assert torch.isfinite(stats).all()                        # no row of the buffer left unwritten
+    got = stats.double().sum(0).cpu()
+    p64 = pre.double().cpu()
+    ref = torch.stack([p64.sum(dim=(0, 2)), (p64 * p64).sum(dim=(0, 2))], dim=1)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6
+    assert float(((got[:, 1] - ref[:, 1]).abs() / ref[:, 1]).max()) < 2e-6
+    a = H.bn_finalize(stats, B * T, None, None, None, None, None, 0.1, 1e-5)
+    b = H.bn_finalize(H.channel_stats(pre), B * T, None, None, None, None, None, 0.1, 1e-5)
+    # var = E[x^2] - mean^2 from fp32 partial sums: with a channel mean of 3 sigma both routes carry ~1e-6 * 10
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max() / v.abs().max()) < 2e-5
+    var64 = ref[:, 1] / (B * T) - (ref[:, 0] / (B * T)) ** 2
+    assert float((a[1].double().cpu() * (var64 + 1e-5).sqrt() - 1).abs().max()) < 2e-5       # invstd against fp64
+
+
 def test_producers_publish_their_own_maximum(h2_mode, H):
     """The elementwise kernels and the conv epilogue publish max|output| themselves (per-workgroup partial maxima);
     the consuming contraction then needs no pass over the tensor."""
