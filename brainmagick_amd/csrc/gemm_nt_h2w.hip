@@ -170,8 +170,15 @@ extern "C" int bm_debug_trace_read(long long* out) {
 // inside or outside a row, pieces outside are fetched at an out-of-range offset (zeros), and A needs no per-value
 // edge scales.
 // TS ("transposed store"): part[split][c][m] (row length M) instead of part[split][m][c]; needs M % 4 == 0.
-template <int KS, int MW, int NS, bool RS = false, bool TS = false>
+// FL ("flat time axis", with RS): the S segments of T samples are contracted as ONE axis of S * T samples cut into
+// 32-sample stages, instead of ceil(T / 32) stages per segment -- T = 360 wastes 24 of every 384 samples (6.25 % of the
+// MFMAs) otherwise.  Needs T % 4 == 0 (a lane's 4-sample piece then lies inside one segment), T >= 64 and both
+// tensors below 2 GB (one descriptor each); a piece's segment and local time are per-lane state, advanced by
+// additions; the X samples a tap shift pushes outside their segment are zeroed by the per-value scales, as at the
+// segment edges of the per-segment walk.
+template <int KS, int MW, int NS, bool RS = false, bool TS = false, bool FL = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
+    static_assert(!FL || RS, "the flat walk relies on the row-scaled A path (pieces inside or outside a row)");
     static_assert((MW == 5 && NS == 3) || (MW == 4 && NS == 2) || (MW == 4 && NS == 4),
                   "tile variants: 320 x 192, 256 x 128, 256 x 256");
     static_assert(!TS || (KS == 1 && !RS), "the transposed partial tile is the score contraction's");
@@ -206,13 +213,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     const int m0 = tm * BM, c0 = tc * BC;
 
     const int cps = (a.T + HG_K - 1) / HG_K;
-    const long nchunks = (long)a.S * cps;
+    const long nchunks = FL ? ((long)a.S * a.T + HG_K - 1) / HG_K : (long)a.S * cps;
     const long q_begin = nchunks * split / a.nsplit;
     const long q_end = nchunks * (split + 1) / a.nsplit;
     const int nst = (int)(q_end - q_begin);
     const int halo = KS == 3 ? a.dil : 0;
-    const int a_bytes = (int)(((long)(a.M - 1) * a.a_rstride + a.T) * 4);
-    const int x_bytes = (int)(((long)(a.Cn - 1) * a.x_rstride + a.T) * 4);
+    const int a_bytes = (int)(((FL ? (long)(a.S - 1) * a.a_sstride : 0) + (long)(a.M - 1) * a.a_rstride + a.T) * 4);
+    const int x_bytes = (int)(((FL ? (long)(a.S - 1) * a.x_sstride : 0) + (long)(a.Cn - 1) * a.x_rstride + a.T) * 4);
     float sa, sa_inv, sx, sx_inv;
     hg_scale_from_amax(bm_amax_load(a.a_amax), sa, sa_inv);
     hg_scale_from_amax(bm_amax_load(a.x_amax), sx, sx_inv);
@@ -260,10 +267,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
             hg_scale_from_amax(m < a.M ? a.a_row_amax[m] : 0.f, sarow[i], inv_unused);
         }
     }
+    // (T0_ = first sample of the chunk in the staging set, local to its segment; FL: this lane's piece may already
+    // belong to the next segment -- its own local time lt_st is used instead)
 #define HG_SET_SCALES(T0_)                                                                        \
     {                                                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                           \
-            const int ta = (T0_) + 4 * pl + r;                                                    \
+            const int ta = (FL ? lt_st : (T0_) + 4 * pl) + r;                                     \
             if constexpr (!RS) sva[r] = ta < a.T ? sa : 0.f;                                      \
             _Pragma("unroll") for (int j = 0; j < NXS; ++j) {                                     \
                 const int tx = ta + (KS == 3 ? (j - 1) * a.dil : 0);                              \
@@ -273,22 +282,49 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     }
 
     int ld_q = 0;
-    int ld_s = (int)(q_begin / cps);
-    int ld_c = (int)(q_begin - (long)ld_s * cps);
-    // segment descriptors, rebuilt only when the cursor enters a new segment
+    int ld_s = FL ? 0 : (int)(q_begin / cps);
+    int ld_c = FL ? 0 : (int)(q_begin - (long)ld_s * cps);
+    // segment descriptors, rebuilt only when the cursor enters a new segment (FL: the whole tensors, once)
     __amdgpu_buffer_rsrc_t qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);
     __amdgpu_buffer_rsrc_t qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);
     int vn, vx[NXS];                                   // byte offset of the chunk to fetch (X: per tap)
     unsigned vna = 0;                                  // RS: the same for A, out of range when this lane's piece lies past T
+    // FL: this lane's piece of the chunk at the cursor -- segment ls, local time lt (a multiple of 4), byte offsets
+    // la / lx of (segment start + lt - 4 pl) in A / X; cur_t0 = local time of the chunk's first sample (wave-uniform)
+    int ls = 0, lt = 0, la = 0, lx = 0, cur_t0 = 0, lt_st = 0;
+    if constexpr (FL) {
+        const long f0 = q_begin * HG_K;
+        const int s0 = (int)(f0 / a.T);
+        cur_t0 = (int)(f0 - (long)s0 * a.T);
+        ls = s0;
+        lt = cur_t0 + 4 * pl;
+        if (lt >= a.T) { lt -= a.T; ++ls; }
+        la = (int)(((long)ls * a.a_sstride + lt - 4 * pl) * 4);
+        lx = (int)(((long)ls * a.x_sstride + lt - 4 * pl) * 4);
+    }
 #define HG_CHUNK_OFFSETS()                                                                        \
     {                                                                                             \
-        vn = ld_c * (HG_K * 4);                                                                   \
-        if constexpr (RS) vna = (ld_c * HG_K + 4 * pl < a.T) ? (unsigned)vn : 0x7f000000u;        \
+        if constexpr (FL) {                                                                       \
+            vn = lx;                                                                              \
+            vna = ls < a.S ? (unsigned)la : 0x7f000000u;                                          \
+        } else {                                                                                  \
+            vn = ld_c * (HG_K * 4);                                                               \
+            if constexpr (RS) vna = (ld_c * HG_K + 4 * pl < a.T) ? (unsigned)vn : 0x7f000000u;    \
+        }                                                                                         \
         _Pragma("unroll") for (int j = 0; j < NXS; ++j) vx[j] = vn + (KS == 3 ? (j - 1) * a.dil * 4 : 0); \
     }
 #define HG_ADVANCE()                                                                              \
     if (++ld_q < nst) {                                /* else: stays on the last chunk */        \
-        if (++ld_c == cps) {                                                                      \
+        if constexpr (FL) {                                                                       \
+            cur_t0 += HG_K;                                                                       \
+            if (cur_t0 >= a.T) cur_t0 -= a.T;                                                     \
+            lt += HG_K; la += HG_K * 4; lx += HG_K * 4;                                           \
+            if (lt >= a.T) {                                                                      \
+                lt -= a.T; ++ls;                                                                  \
+                la += ((int)a.a_sstride - a.T) * 4;                                               \
+                lx += ((int)a.x_sstride - a.T) * 4;                                               \
+            }                                                                                     \
+        } else if (++ld_c == cps) {                                                               \
             ld_c = 0; ++ld_s;                                                                     \
             qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                                \
             qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                                \
@@ -345,8 +381,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 
     if (nst > 0) {
         // chunk 0 -> buffer 0, chunk 1 -> staging set
+        // HG_MARK: remember where the chunk about to be fetched starts (wave-uniform t0c; FL: this lane's lt_st)
+#define HG_MARK() { t0c = FL ? cur_t0 : ld_c * HG_K; if constexpr (FL) lt_st = lt; }
         HG_CHUNK_OFFSETS()
-        int t0c = ld_c * HG_K;
+        int t0c;
+        HG_MARK()
 #pragma unroll
         for (int i = 0; i < NP; ++i) HG_FETCH(i)
         HG_ADVANCE()
@@ -354,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) HG_STORE(i, reinterpret_cast<char*>(lds))
         HG_CHUNK_OFFSETS()
-        t0c = ld_c * HG_K;
+        HG_MARK()
 #pragma unroll
         for (int i = 0; i < NP; ++i) HG_FETCH(i)
         HG_ADVANCE()
@@ -381,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
             if (edge || was_edge) HG_SET_SCALES(t0c)
             was_edge = edge;
             HG_CHUNK_OFFSETS()
-            t0c = ld_c * HG_K;
+            HG_MARK()
             HG_T(1)
             // One slot per MFMA, in source order (scheduling fence after each): the MFMA, then at most one
             // fragment read and one sub-step of a piece -- a lone wavefront per SIMD issues one instruction every
@@ -447,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #endif
     }
 #undef HG_SET_SCALES
+#undef HG_MARK
 #undef HG_CHUNK_OFFSETS
 #undef HG_ADVANCE
 #undef HG_FETCH
@@ -535,6 +575,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #endif
 }
 
+// BM_GEMM_FLAT_AXIS=0: per-segment stages also where the flat walk applies (A/B switch)
+static int hg_flat_axis() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("BM_GEMM_FLAT_AXIS");
+        on = !(e && e[0] == '0');
+    }
+    return on;
+}
+
 // tile family of a shape: 0 = not covered, 1 = 320 x 192 (<KS,5,3>), 2 = 256 x 128 (<1,4,2>)
 static int hg_family(int S, int G, int M, int Cn, int T, int KS, int dil, bool ordered) {
     static int wide = -1;
@@ -569,13 +619,13 @@ extern "C" int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T)
     return (int)want;
 }
 
-template <int KS, int MW, int NS, bool RS = false, bool TS = false>
+template <int KS, int MW, int NS, bool RS = false, bool TS = false, bool FL = false>
 static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     constexpr int PLANE = 4 * (64 * MW + 2) + NS * 4 * HG_XQ;
     const size_t lds = (size_t)2 * 2 * PLANE * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_h2w_kernel<KS, MW, NS, RS, TS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_h2w_kernel<KS, MW, NS, RS, TS, FL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "gemm_nt_h2w: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -583,7 +633,7 @@ static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     g.tiles_m = cdiv(g.M, 64 * MW);
     g.tiles_c = cdiv(g.Cn, KS == 3 ? 64 : 64 * NS);
     const long nblocks = (long)g.tiles_m * g.tiles_c * g.nsplit;
-    hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS, RS, TS>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS, RS, TS, FL>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
     return bm_check_launch("gemm_nt_h2w");
 }
 
@@ -611,6 +661,13 @@ static int gemm_nt_h2_impl(const float* a, long a_sstride, long a_rstride, const
     hipStream_t s = (hipStream_t)stream;
     // per-row scales of A: the 320-row tiles, rows contiguous in time (pieces of 4 samples never straddle a row)
     const bool rs = a_row_amax && fam == 1 && T % 4 == 0 && a_rstride % 4 == 0 && a_sstride % 4 == 0;
+    // flat time axis (no per-segment padding of T to a multiple of 32): row-scaled 3-tap weight gradients whose
+    // tensors fit one 2 GB descriptor each
+    const bool flat = rs && KS == 3 && hg_flat_axis() && T % HG_K != 0 && T >= 2 * HG_K && S > 1 &&
+                      ((long)(S - 1) * a_sstride + (long)(M - 1) * a_rstride + T) * 4 < 0x7f000000L &&
+                      ((long)(S - 1) * x_sstride + (long)(Cn - 1) * x_rstride + T) * 4 < 0x7f000000L &&
+                      a_sstride >= T && x_sstride >= T && x_sstride % 4 == 0;
+    if (flat) return launch_gemm_nt_h2w<3, 5, 3, true, false, true>(g, s);
     if (KS == 3) return rs ? launch_gemm_nt_h2w<3, 5, 3, true>(g, s) : launch_gemm_nt_h2w<3, 5, 3>(g, s);
     if (fam == 2) return launch_gemm_nt_h2w<1, 4, 2>(g, s);
     return rs ? launch_gemm_nt_h2w<1, 5, 3, true>(g, s) : launch_gemm_nt_h2w<1, 5, 3>(g, s);

@@ -220,6 +220,35 @@ def test_row_scaled_weight_gradient_shapes(h2_mode, H, KS, T):
         assert row_err.max().item() < 2e-6, row_err.max().item()
 
 
+@pytest.mark.parametrize("B,T,dil,Cin,M", [(7, 360, 1, 320, 320), (5, 360, 16, 320, 320), (9, 100, 4, 320, 320),
+                                            (13, 68, 2, 64, 320), (3, 360, 8, 640, 320), (33, 76, 16, 320, 270)])
+def test_weight_gradient_over_a_flat_time_axis(h2_mode, H, B, T, dil, Cin, M):
+    """Row-scaled 3-tap weight gradients with T % 32 != 0 walk the B segments as ONE axis of B * T samples (no padding
+    of every segment to a multiple of 32): a stage then straddles segment boundaries, a lane's piece belongs to the
+    segment its own local time says, and the samples a tap shift moves outside their segment are zeroed per value.
+    Boundaries at every position of a stage (T = 68, 76, 100), the largest dilation, a total that is not a multiple
+    of 32 (B * T % 32 != 0), more segments than splits -- against fp64, row-wise."""
+    g = _gen(B * T + dil)
+    dy = torch.randn(B, M, T, generator=g) * torch.logspace(0, -4, M)[None, :, None]
+    x = torch.randn(B, Cin, T, generator=g)
+    # make the segment edges count: large values in the first / last samples of every segment
+    x[:, :, :2] *= 8
+    x[:, :, -2:] *= 8
+    dy[:, :, :1] *= 4
+    dy[:, :, -1:] *= 4
+    from brainmagick_amd._lib import lib
+    assert lib().bm_gemm_nt_h2_covers(M, Cin, 3, B, T, 1, dil, 0)
+    dyg = dy.cuda()
+    dyg._bm_row_amax = (dyg._version, dyg.data_ptr(), dyg.abs().amax(dim=(0, 2)).contiguous())
+    dw = H.gemm_nt(dyg, x.cuda(), B, M, Cin, T, 3, dil)[0]
+    ref = _wgrad_ref(dy, x, 3, dil)
+    assert rel_l2(dw, ref) < GRAD_TOL
+    row_err = (dw.double().cpu() - ref).norm(dim=(1, 2)) / ref.norm(dim=(1, 2))
+    assert row_err.max().item() < 2e-6, row_err.max().item()
+    tap_err = (dw.double().cpu() - ref).norm(dim=(0, 1)) / ref.norm(dim=(0, 1))        # per tap: the shifted edges
+    assert tap_err.max().item() < 2e-6, tap_err
+
+
 @pytest.mark.parametrize("decades", [0, 4, 8])
 def test_per_channel_spread_conv_output_channels(h2_mode, H, decades):
     g = _gen(50 + decades)
