@@ -133,6 +133,9 @@ __device__ __forceinline__ float bm_amax_load(const float* slot) {
 int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream);
 // host: fold partials laid out [nsplit][C] into the slot AND into per-channel maxima rows_out[C] (nullable)
 int bm_amax_finalize_rows(const float* ws, int C, int nsplit, float* out, float* rows_out, hipStream_t stream);
+// host: the same launch also folds per-(channel, split) double sums [C][nsplit] into sums_out[C] (out must be non-null)
+int bm_amax_finalize_rows_sums(const float* ws, int C, int nsplit, float* out, float* rows_out,
+                               const double* sum_partial, float* sums_out, hipStream_t stream);
 // host: destination of a producer's maximum for the current mode, and what follows its launch
 int bm_amax_atomic();                                   // 1 only with BM_AMAX_ATOMIC=1 (measured slower, core.hip)
 static inline BmAmaxDst bm_amax_dst(float* amax_out, float* amax_ws) {

@@ -157,28 +157,41 @@ __device__ __forceinline__ float h2_general_blocks(const ConvNNArgs& a, f32x16 (
 }
 
 // BatchNorm statistics of the tile (training-mode conv + BN layers, bm/models/common.py:119): per output row, sum and
-// sum of squares of y_pre = acc + bias over this wavefront's 96 columns, written as partial row (tile, wavefront
-// column) of `stats` [B * ntiles_n * 2][M][2] -- bm_bn_finalize adds the partials in double.  Saves the
+// sum of squares of y_pre = acc + bias over this wavefront's 96 columns, written as partial (tile, wavefront
+// column) of the channel-major `stats` [M][B * ntiles_n * 2][2] -- bm_bn_finalize_cm adds a channel's partials, one
+// contiguous run, in double.  Saves the
 // channel_stats pass over the 118 MB output.  Per row block: the lane's 3 column blocks are summed in registers,
 // then a halving butterfly over the 32 lanes of a half-wavefront (16 + 8 + 4 + 2 + 1 + 1 exchanges for 2 x 16
 // values instead of 5 x 32) leaves row q = 8 b4 + 4 b3 + 2 b2 + b1 (bk = bit k of the lane) in each lane.
 template <int MW>
 __device__ __forceinline__ void h2_tile_stats(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* epl /* lane's bias rows */,
-                                              float* stats_tile /* + (tile * 2 + wn) * M * 2 */, int row0 /* first row of the lane's blocks */,
-                                              int col0, int lane) {
+                                              float* stats_tile /* + (tile * 2 + wn) * 2 */, long row_stride /* floats between channels */,
+                                              int row0 /* first row of the lane's blocks */, int col0, int lane) {
     const bool c0ok = col0 < a.T, c1ok = col0 + 32 < a.T, c2ok = col0 + 64 < a.T;
+    // wave-uniform: every column of the wavefront's 96 lies inside T (3 of the 4 wavefront tiles of a T = 360 segment)
+    const bool all_in = __builtin_amdgcn_readfirstlane(col0 - (lane & 31)) + 95 < a.T;
     const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
     h2_static_for<MW>([&](auto mc) __attribute__((always_inline)) {
         constexpr int mt = decltype(mc)::value;
         float s1[16], s2[16];
+        if (all_in) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bias = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
-            const float v0 = c0ok ? acc[mt][0][r] + bias : 0.f;
-            const float v1 = c1ok ? acc[mt][1][r] + bias : 0.f;
-            const float v2 = c2ok ? acc[mt][2][r] + bias : 0.f;
-            s1[r] = (v0 + v1) + v2;
-            s2[r] = fmaf(v0, v0, fmaf(v1, v1, v2 * v2));
+            for (int r = 0; r < 16; ++r) {
+                const float bias = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+                const float v0 = acc[mt][0][r] + bias, v1 = acc[mt][1][r] + bias, v2 = acc[mt][2][r] + bias;
+                s1[r] = (v0 + v1) + v2;
+                s2[r] = fmaf(v0, v0, fmaf(v1, v1, v2 * v2));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bias = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+                const float v0 = c0ok ? acc[mt][0][r] + bias : 0.f;
+                const float v1 = c1ok ? acc[mt][1][r] + bias : 0.f;
+                const float v2 = c2ok ? acc[mt][2][r] + bias : 0.f;
+                s1[r] = (v0 + v1) + v2;
+                s2[r] = fmaf(v0, v0, fmaf(v1, v1, v2 * v2));
+            }
         }
 #define H2_FOLD(N_, BIT_, MASK_)                                                                  \
         _Pragma("unroll") for (int i = 0; i < N_; ++i) {                                          \
@@ -198,7 +211,7 @@ __device__ __forceinline__ void h2_tile_stats(const ConvNNArgs& a, f32x16 (&acc)
         const int q = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
         const int row = row0 + mt * 32 + (q & 3) + 8 * (q >> 2);
         if (!(lane & 1) && row < a.M)
-            *reinterpret_cast<float2*>(stats_tile + (long)row * 2) = float2{s1[0], s2[0]};
+            *reinterpret_cast<float2*>(stats_tile + (long)row * row_stride) = float2{s1[0], s2[0]};
     });
 }
 
@@ -510,8 +523,8 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     // layers in 320-row tiles) take the same path with a row predicate.
     if (a.stats)            // training-mode BatchNorm layers: the host allows it only with y_pre alone (simple path)
         h2_tile_stats<MW>(a, acc, ep + wm * (MW * 32) + 4 * h,
-                          a.stats + ((long)((b * a.ntiles_n + ntile) * 2 + wn) * a.M) * 2, m0 + wm * (MW * 32) + 4 * h,
-                          n0 + wn * (NW * 32) + nl, lane);
+                          a.stats + (long)((b * a.ntiles_n + ntile) * 2 + wn) * 2, (long)a.B * a.ntiles_n * 4,
+                          m0 + wm * (MW * 32) + 4 * h, n0 + wn * (NW * 32) + nl, lane);
     const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE;
     if (simple) {
         H2Simple<MW> e;

@@ -56,7 +56,9 @@ int bm_amax_finalize(const float* ws, int n, float* out, hipStream_t stream) {
 // max over the splits -- the per-channel maxima that give every row of a weight gradient its own f16x2 scale
 // (gemm_nt_h2w.hip, RS kernels) -- and the tensor maximum into the slot, in ONE one-workgroup launch.
 __global__ __launch_bounds__(1024) void amax_finalize_rows_kernel(const float* __restrict__ ws, int C, int nsplit,
-                                                                  float* __restrict__ out, float* __restrict__ rows_out) {
+                                                                  float* __restrict__ out, float* __restrict__ rows_out,
+                                                                  const double* __restrict__ sum_partial,
+                                                                  float* __restrict__ sums_out) {
     __shared__ float sh[16];
     float m = 0.f;
     for (int c = threadIdx.x; c < C; c += 1024) {
@@ -64,6 +66,11 @@ __global__ __launch_bounds__(1024) void amax_finalize_rows_kernel(const float* _
         for (int s = 0; s < nsplit; ++s) r = fmaxf(r, ws[(long)s * C + c]);
         if (rows_out) rows_out[c] = r;
         m = fmaxf(m, r);
+        if (sum_partial) {                  // the same launch folds the producer's per-(channel, split) sums (bias gradient)
+            double t = 0;
+            for (int s = 0; s < nsplit; ++s) t += sum_partial[(long)c * nsplit + s];
+            sums_out[c] = (float)t;
+        }
     }
     m = bm_wave_max(m);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
@@ -78,7 +85,16 @@ __global__ __launch_bounds__(1024) void amax_finalize_rows_kernel(const float* _
 
 int bm_amax_finalize_rows(const float* ws, int C, int nsplit, float* out, float* rows_out, hipStream_t stream) {
     if (!out) return BM_OK;
-    hipLaunchKernelGGL(amax_finalize_rows_kernel, dim3(1), dim3(1024), 0, stream, ws, C, nsplit, out, rows_out);
+    hipLaunchKernelGGL(amax_finalize_rows_kernel, dim3(1), dim3(1024), 0, stream, ws, C, nsplit, out, rows_out,
+                       (const double*)nullptr, (float*)nullptr);
+    return bm_check_launch("amax_finalize_rows");
+}
+
+// ... and, in the same launch, sums_out[c] = sum_split sum_partial[c][split] (doubles; the bias gradient of the layer)
+int bm_amax_finalize_rows_sums(const float* ws, int C, int nsplit, float* out, float* rows_out,
+                               const double* sum_partial, float* sums_out, hipStream_t stream) {
+    hipLaunchKernelGGL(amax_finalize_rows_kernel, dim3(1), dim3(1024), 0, stream, ws, C, nsplit, out, rows_out,
+                       sum_partial, sums_out);
     return bm_check_launch("amax_finalize_rows");
 }
 

@@ -48,7 +48,7 @@ __device__ void block_sum(double (&v)[NV], double* sh) {
 // torch semantics: normalise with the biased variance, update running_var with the unbiased one,
 // running = (1 - momentum) * running + momentum * batch, num_batches_tracked += 1.
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, double count,
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, long tstride, long cstride, int ntiles, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, long* num_batches,
                                    float momentum, float eps, float* __restrict__ mean_out,
@@ -57,8 +57,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, 
     const int c = blockIdx.x;
     double s = 0, s2 = 0;
     for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-        s += (double)stats[((long)t * C + c) * 2 + 0];
-        s2 += (double)stats[((long)t * C + c) * 2 + 1];
+        s += (double)stats[(long)t * tstride + (long)c * cstride + 0];
+        s2 += (double)stats[(long)t * tstride + (long)c * cstride + 1];
     }
     s = bm_wave_sum_d(s);
     s2 = bm_wave_sum_d(s2);
@@ -88,10 +88,24 @@ extern "C" int bm_bn_finalize(const float* stats, int ntiles, int C, long count,
                               float* invstd, float* scale, float* shift, void* stream) {
     BM_REQUIRE(stats && mean && invstd && scale && shift, "bn_finalize: null pointer");
     BM_REQUIRE(C > 0 && ntiles > 0 && count > 0, "bn_finalize: bad dims");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, ntiles, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, (long)C * 2, 2L, ntiles, C,
                        (double)count, gamma, beta, running_mean, running_var, num_batches, momentum,
                        eps, mean, invstd, scale, shift);
     return bm_check_launch("bn_finalize");
+}
+
+// The same for channel-major partials stats[C][ntiles][2] (what the wide f16x2 conv writes from its epilogue: a
+// channel's ~1 000 partial rows are then one contiguous run for the workgroup that folds them).
+extern "C" int bm_bn_finalize_cm(const float* stats, int ntiles, int C, long count, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var,
+                                 long* num_batches, float momentum, float eps, float* mean,
+                                 float* invstd, float* scale, float* shift, void* stream) {
+    BM_REQUIRE(stats && mean && invstd && scale && shift, "bn_finalize_cm: null pointer");
+    BM_REQUIRE(C > 0 && ntiles > 0 && count > 0, "bn_finalize_cm: bad dims");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, 2L, (long)ntiles * 2, ntiles, C,
+                       (double)count, gamma, beta, running_mean, running_var, num_batches, momentum,
+                       eps, mean, invstd, scale, shift);
+    return bm_check_launch("bn_finalize_cm");
 }
 
 // eval mode: scale/shift from the running statistics.
@@ -341,12 +355,16 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
                            amax_dst, bn_apply_reverse());
     }
+    // the (channel, split) grid's partials are per channel already: ONE launch folds them into the tensor slot, the
+    // per-channel maxima and the bias gradient (two-stage mode; otherwise the sums get their own launch)
+    if (amax_dst.ws && amax_out && dbias) {
+        if (int rc = bm_check_launch("act_bn_bwd")) return rc;
+        return bm_amax_finalize_rows_sums(amax_dst.ws, C, nsplit, amax_out, amax_rows_out, dy_partial, dbias, s);
+    }
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dy_partial,
                            dbias, C, nsplit);
     if (int rc = bm_check_launch("act_bn_bwd")) return rc;
-    // the (channel, split) grid's partials are per channel already: one launch folds them into the tensor slot and
-    // the per-channel maxima (two-stage mode only)
     if (amax_dst.ws) return bm_amax_finalize_rows(amax_dst.ws, C, nsplit, amax_out, amax_rows_out, s);
     return bm_amax_done(amax_dst, C * nsplit, amax_out, s);
 }
@@ -593,6 +611,10 @@ extern "C" int bm_glu_bwd(const float* dout, const float* u, float* du, float* d
     else
         hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(H, nsplit), dim3(256), 0, s, dout, u, du, partial, B, H, T,
                            amax_dst);
+    if (amax_dst.ws && amax_out && dbias) {
+        if (int rc = bm_check_launch("glu_bwd")) return rc;
+        return bm_amax_finalize_rows_sums(amax_dst.ws, 2 * H, nsplit, amax_out, amax_rows_out, partial, dbias, s);
+    }
     if (dbias)
         hipLaunchKernelGGL(finalize_channel_sums_kernel, dim3(cdiv(2 * H, 256)), dim3(256), 0, s, partial,
                            dbias, 2 * H, nsplit);

@@ -384,8 +384,11 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
         y_out = torch.empty(B, M, T, device=x.device, dtype=torch.float32) if want_out else None
     stats = None
     if want_stats:
-        ntiles = lib().bm_conv_h2_stats_tiles(B, T) if mode == "f16x2" else lib().bm_conv_stats_tiles(B, T)
-        stats = torch.empty(ntiles, M, 2, device=x.device, dtype=torch.float32)
+        if mode == "f16x2":     # channel-major: a channel's partials are one contiguous run for bn_finalize
+            stats = torch.empty(M, lib().bm_conv_h2_stats_tiles(B, T), 2, device=x.device, dtype=torch.float32)
+            stats._bm_channel_major = True
+        else:
+            stats = torch.empty(lib().bm_conv_stats_tiles(B, T), M, 2, device=x.device, dtype=torch.float32)
     if res is not None:
         _req(res, "conv_nn.res")
         assert res.shape == (B, M, T), (res.shape, (B, M, T))
@@ -617,10 +620,11 @@ def sum_over_batch(x: torch.Tensor) -> torch.Tensor:
 def bn_finalize(stats, count: int, gamma, beta, running_mean, running_var, num_batches,
                 momentum: float, eps: float):
     _req(stats, "bn_finalize.stats")
-    ntiles, C, _ = stats.shape
+    channel_major = getattr(stats, "_bm_channel_major", False)
+    (C, ntiles, _) = stats.shape if channel_major else (stats.shape[1], stats.shape[0], 2)
     mean, invstd, scale, shift = (torch.empty(C, device=stats.device, dtype=torch.float32)
                                   for _ in range(4))
-    check(lib().bm_bn_finalize(_p(stats), ntiles, C, count, _p(_opt(gamma, "gamma")),
+    check((lib().bm_bn_finalize_cm if channel_major else lib().bm_bn_finalize)(_p(stats), ntiles, C, count, _p(_opt(gamma, "gamma")),
                                _p(_opt(beta, "beta")), _p(_opt(running_mean, "running_mean")),
                                _p(_opt(running_var, "running_var")),
                                _p(_opt(num_batches, "num_batches", torch.int64)), momentum, eps,

@@ -132,8 +132,9 @@ int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
  * is set to 1 when x holds an inf or a nan. */
 int bm_amax_checked(const float* x, long n, float* out, float* amax_ws, int* nonfinite_flag, void* stream);
 /* `stats` (nullable; only together with y_pre alone, no affine / activation / residual: the training-mode BatchNorm
- * layers): [bm_conv_h2_stats_tiles(B, T)][M][2] per-(segment, column tile, wavefront column) partial sums and sums
- * of squares of y_pre, every row written; input of bm_bn_finalize with ntiles = bm_conv_h2_stats_tiles(B, T). */
+ * layers): CHANNEL-MAJOR [M][bm_conv_h2_stats_tiles(B, T)][2] per-(segment, column tile, wavefront column) partial
+ * sums and sums of squares of y_pre, every entry written; input of bm_bn_finalize_cm with ntiles =
+ * bm_conv_h2_stats_tiles(B, T). */
 int bm_conv_h2_stats_tiles(int B, int T);
 int bm_conv1d_nn_h2(const float* x, long x_bstride, const float* x_amax, const void* wpacked, const int* widx,
                     const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
@@ -177,6 +178,11 @@ int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x, l
 
 /* ---- BatchNorm1d / activation / residual / GLU (norm_act.hip)  bm/models/common.py:113-151 ---- */
 int bm_bn_finalize(const float* stats, int ntiles, int C, long count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, long* num_batches,
+                   float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                   void* stream);
+/* The same for channel-major partials stats[C][ntiles][2] (bm_conv1d_nn_h2's `stats`). */
+int bm_bn_finalize_cm(const float* stats, int ntiles, int C, long count, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, long* num_batches,
                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                    void* stream);

@@ -392,7 +392,8 @@ def test_conv_epilogue_batchnorm_statistics(h2_mode, H, Cin, M, KS, dil, T, B):
     pre2, _, _ = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True, want_out=False)
     assert torch.equal(pre, pre2)                             # the statistics do not disturb the output
     assert torch.isfinite(stats).all()                        # no row of the buffer left unwritten
-    got = stats.double().sum(0).cpu()
+    assert stats.shape[0] == M and stats._bm_channel_major         # [M][tiles][2]
+    got = stats.double().sum(1).cpu()
     p64 = pre.double().cpu()
     ref = torch.stack([p64.sum(dim=(0, 2)), (p64 * p64).sum(dim=(0, 2))], dim=1)
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6
