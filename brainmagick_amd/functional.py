@@ -413,9 +413,10 @@ class ClipLossFn(torch.autograd.Function):
             # conv epilogue's residual operand, written in place
             for r0, rows in blocks:
                 wp = H.pack_weights(dscaled.view(-1)[r0:], 1, B, rows, 1, 0, Bc, 1, 0, alpha=alpha, shape=(K, 1))
-                blk = cand2[r0:r0 + rows] if len(blocks) == 1 else H.share_amax(candidate, cand2[r0:r0 + rows])
-                _, dest, _ = H.conv_nn(blk.view(1, rows, K), wp, B, 1, 1, res=dest, out=dest)
-            dest = dest.view(ctx.shape)
+                # (views are new tensor objects: hand the candidates' published maximum on instead of re-scanning them)
+                blk = H.share_amax(candidate, cand2[r0:r0 + rows].view(1, rows, K))
+                _, dest, _ = H.conv_nn(blk, wp, B, 1, 1, res=dest, out=dest)
+            dest = H.share_amax(dest, dest.view(ctx.shape))
         dcand = None
         if ctx.needs_input_grad[1]:
             # learnable candidates (DeepMel feature model): dcand_o = sum_b dscaled[b,o] est_b - coef_o cand_o

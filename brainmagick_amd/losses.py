@@ -45,6 +45,10 @@ class ClipLoss(torch.nn.Module):
                 lo = int((-origin + tmin) * rate)
             if tmax is not None:
                 hi = int((-origin + tmax) * rate)
+        if lo == 0 and hi == estimates.shape[-1] and hi == candidates.shape[-1]:
+            # no crop: the tensors themselves go on (a slice would be a new object without the maxima / candidate
+            # norms their producers published)
+            return estimates, candidates
         return estimates[..., lo:hi], candidates[..., lo:hi]
 
     def _prepare(self, estimates, candidates):
