@@ -593,3 +593,36 @@ def test_c_level_stdout_is_parked_on_stderr_while_a_communicator_comes_up():
     assert p.returncode == 0, p.stderr
     assert p.stdout.split() == ["before", "after-c", "after"], p.stdout
     assert "BANNER" in p.stderr
+
+
+def test_clip_loss_trim_keeps_the_tensors_when_nothing_is_cropped():
+    """`ClipLoss.trim_samples` (bm/losses.py:50-75) slices both tensors; without tmin / tmax the slice is the
+    identity, and the tensors themselves must go on -- a view is a new object without the maxima / candidate norms
+    their producers attached (three stand-alone passes per step otherwise).  With a crop the result equals the
+    reference's slice."""
+    from types import SimpleNamespace
+    from brainmagick_amd.losses import ClipLoss
+    est, cand = torch.randn(3, 4, 50), torch.randn(5, 4, 50)
+    loss = ClipLoss()
+    a, b = loss.trim_samples(est, cand)
+    assert a is est and b is cand
+    loss = ClipLoss(tmin=0.1, tmax=0.3, dset_args=SimpleNamespace(tmin=-0.1, sample_rate=100))
+    a, b = loss.trim_samples(est, cand)
+    assert a.shape[-1] == 20 and torch.equal(a, est[..., 20:40]) and torch.equal(b, cand[..., 20:40])
+
+
+def test_score_kernel_shape_rules():
+    """Host-side rules of `bm_clip_scores_h2`: which shapes it takes, and its split counts (no GPU needed)."""
+    from brainmagick_amd import _lib
+    L = _lib.lib()
+    T = 360
+    assert L.bm_clip_scores_h2_covers(256, 256, 120 * T) and L.bm_clip_scores_h2_covers(256, 256, 1024 * T)
+    assert L.bm_clip_scores_h2_covers(256, 2048, 120 * T)
+    assert not L.bm_clip_scores_h2_covers(256, 2048, 1024 * T)        # 3 GB of candidates: walked in row blocks
+    assert not L.bm_clip_scores_h2_covers(8, 8, 120 * T)              # a tile would be almost all padding
+    assert not L.bm_clip_scores_h2_covers(256, 254, 120 * T)          # 16-byte partial stores need Bc % 4 == 0
+    # short K: 128-estimate tiles, two per split -> 128 splits fill 256 CUs; long K: one 256 x 256 tile per split
+    assert L.bm_clip_scores_h2_suggest_splits(256, 256, 120 * T) == 128
+    assert L.bm_clip_scores_h2_suggest_splits(256, 256, 1024 * T) == 256
+    assert L.bm_clip_scores_h2_suggest_splits(256, 2048, 120 * T) == 32
+    assert L.bm_conv_h2_stats_tiles(256, 360) == 256 * 2 * 2
