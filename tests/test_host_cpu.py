@@ -626,3 +626,26 @@ def test_score_kernel_shape_rules():
     assert L.bm_clip_scores_h2_suggest_splits(256, 256, 1024 * T) == 256
     assert L.bm_clip_scores_h2_suggest_splits(256, 2048, 120 * T) == 32
     assert L.bm_conv_h2_stats_tiles(256, 360) == 256 * 2 * 2
+
+
+def test_header_prototypes_match_the_definitions():
+    """`include/bm_hip.h` is what `_lib.py` parses into ctypes prototypes, but the kernels' translation units do not
+    include it -- a drifted parameter list would silently pass mis-typed arguments.  Every `extern "C"` definition of
+    csrc/*.hip is re-declared next to the header in one translation unit; C linkage forbids overloads, so g++ rejects
+    any definition whose parameter types differ from the header's."""
+    import tempfile
+    decls, names = [], set()
+    for f in sorted((ROOT / "brainmagick_amd" / "csrc").glob("*.hip")):
+        for m in re.finditer(r'extern\s+"C"\s+((?:const\s+)?[\w\*\s]+?)\s*\b(bm_\w+)\s*\(([^)]*)\)\s*\{',
+                             f.read_text(), flags=re.S):
+            decls.append(f"{m.group(1).strip()} {m.group(2)}({' '.join(m.group(3).split())});")
+            names.add(m.group(2))
+    header = (ROOT / "include" / "bm_hip.h").read_text()
+    declared = set(re.findall(r"^(?:int|long|const char\*|void)\s+(bm_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 85 and declared <= names, sorted(declared - names)
+    with tempfile.TemporaryDirectory() as tmp:
+        tu = Path(tmp) / "check.cpp"
+        tu.write_text('#include "bm_hip.h"\nextern "C" {\n' + "\n".join(decls) + "\n}\nint main() { return 0; }\n")
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{ROOT / 'include'}", str(tu)],
+                           capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]
