@@ -56,28 +56,37 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
-    # one object per translation unit, compiled concurrently (the wide-tile kernels take ~40 s each), then linked
+    # one object per translation unit, compiled concurrently (the wide-tile kernels take ~40 s each), then linked.
+    # Objects are kept under build/obj (git-ignored): a unit is recompiled when it, or any header, is newer than
+    # its object -- `force` recompiles everything (what __graft_entry__.build() does).
     import concurrent.futures
-    import tempfile
-    with tempfile.TemporaryDirectory(prefix="bmhip_build_") as tmp:
-        def compile_one(src: Path):
-            obj = Path(tmp) / (src.stem + ".o")
-            cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
-            if verbose:
-                print(" ".join(cmd))
-            proc = subprocess.run(cmd, capture_output=True, text=True)
-            if proc.returncode != 0:
-                raise BmHipError(f"hipcc failed on {src.name}:\n{proc.stdout}\n{proc.stderr}")
+    objdir = ROOT.parent / "build" / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
+    newest_header = max([p.stat().st_mtime for p in CSRC.glob("*.h")] + [0.0])
+
+    def compile_one(src: Path):
+        obj = objdir / (src.stem + ".o")
+        if not force and obj.exists() and obj.stat().st_mtime >= max(src.stat().st_mtime, newest_header):
             return obj
-        workers = max(1, min(len(sources), os.cpu_count() or 1, 8))
-        with concurrent.futures.ThreadPoolExecutor(workers) as pool:
-            objects = list(pool.map(compile_one, sources))
-        cmd = [hipcc, *flags, "-shared", *map(str, objects), "-o", str(LIB_PATH)]
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
-            raise BmHipError(f"hipcc link failed:\n{proc.stdout}\n{proc.stderr}")
+            raise BmHipError(f"hipcc failed on {src.name}:\n{proc.stdout}\n{proc.stderr}")
+        return obj
+    workers = max(1, min(len(sources), os.cpu_count() or 1, 8))
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        objects = list(pool.map(compile_one, sources))
+    for stale in objdir.glob("*.o"):            # a source file that went away
+        if stale.stem not in {src.stem for src in sources}:
+            stale.unlink()
+    cmd = [hipcc, *flags, "-shared", *map(str, objects), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise BmHipError(f"hipcc link failed:\n{proc.stdout}\n{proc.stderr}")
     return LIB_PATH
 
 

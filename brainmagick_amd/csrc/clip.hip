@@ -149,7 +149,8 @@ __device__ __forceinline__ float clip_block_sum(float v, float* sh) {
 __global__ __launch_bounds__(256) void clip_ce_kernel(const float* __restrict__ part, int nsplit,
                                                       const float* __restrict__ inv_norm, float* __restrict__ scores,
                                                       float* __restrict__ probs, float* __restrict__ dscaled,
-                                                      float* __restrict__ loss_row, int B, int Bc, int target_offset) {
+                                                      float* __restrict__ loss_row, int B, int Bc, int target_offset,
+                                                      const float* __restrict__ col_valid) {
     __shared__ float sh[4];
     const int b = blockIdx.x;
     const long per = (long)B * Bc;
@@ -169,6 +170,9 @@ __global__ __launch_bounds__(256) void clip_ce_kernel(const float* __restrict__ 
         }
         for (; k < nsplit; ++k) s += p[(long)k * per];
         s *= inv_norm[o];
+        // a masked candidate (padding row of a rank that rejected segments, Solver negatives="node") never matches:
+        // score -inf -> probability 0, gradient 0
+        if (col_valid && col_valid[o] == 0.f) s = -INFINITY;
         srow[o] = s;
         mx = fmaxf(mx, s);
     }
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void clip_ce_kernel(const float* __restrict__ 
         const float s = srow[o];
         const float pr = expf(s - mx) * inv;
         if (probs) probs[(long)b * Bc + o] = pr;
-        if (dscaled) dscaled[(long)b * Bc + o] = (pr - (o == tgt ? 1.f : 0.f)) / (float)B * inv_norm[o];
+        if (dscaled) dscaled[(long)b * Bc + o] = s == -INFINITY ? 0.f : (pr - (o == tgt ? 1.f : 0.f)) / (float)B * inv_norm[o];
         if (o == tgt && loss_row) loss_row[b] = lse - s;
     }
 }
@@ -197,9 +201,21 @@ __global__ void mean_kernel(const float* __restrict__ x, int n, float* __restric
     if (threadIdx.x == 0) *out = (float)((sh[0] + sh[1] + sh[2] + sh[3]) / n);
 }
 
+extern "C" int bm_clip_ce_masked(const float* part, int nsplit, const float* inv_norm, const float* col_valid,
+                                 float* scores, float* probs, float* dscaled, float* loss_row, float* loss, int B,
+                                 int Bc, int target_offset, void* stream);
+
 extern "C" int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores,
                           float* probs, float* dscaled, float* loss_row, float* loss, int B, int Bc,
                           int target_offset, void* stream) {
+    return bm_clip_ce_masked(part, nsplit, inv_norm, nullptr, scores, probs, dscaled, loss_row, loss, B, Bc,
+                             target_offset, stream);
+}
+
+// `col_valid` ([Bc] floats, nullable): candidates with col_valid[o] == 0 are masked out of every row's softmax
+extern "C" int bm_clip_ce_masked(const float* part, int nsplit, const float* inv_norm, const float* col_valid,
+                                 float* scores, float* probs, float* dscaled, float* loss_row, float* loss, int B,
+                                 int Bc, int target_offset, void* stream) {
     BM_REQUIRE(part && inv_norm && scores, "clip_ce: null pointer");
     BM_REQUIRE(!loss || (target_offset >= 0 && target_offset + B <= Bc),
                "clip_ce: need at least as many targets as estimates");
@@ -207,7 +223,7 @@ extern "C" int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, 
     if (B == 0) return BM_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(clip_ce_kernel, dim3(B), dim3(256), 0, s, part, nsplit, inv_norm, scores,
-                       probs, dscaled, loss_row, B, Bc, target_offset);
+                       probs, dscaled, loss_row, B, Bc, target_offset, col_valid);
     if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, loss_row, B, loss);
     return bm_check_launch("clip_ce");
 }

@@ -22,6 +22,21 @@ template <> struct Pack<4> {
     __device__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 
+// Walk of the flat (segment, vector) index e = threadIdx.x, threadIdx.x + blockDim.x, ... of a workgroup's
+// [nb segments][TV vectors] slab without a division per element (the (channel, split) kernels below spend a
+// dozen iterations per thread; `e / TV` per iteration was a fifth of their instructions).
+struct SlabWalk {
+    int bl, tv, dbl, dtv, TV;
+    __device__ SlabWalk(int TV_, int first, int step) : TV(TV_) {
+        bl = first / TV_; tv = first - bl * TV_;
+        dbl = step / TV_; dtv = step - dbl * TV_;
+    }
+    __device__ void next() {
+        tv += dtv; bl += dbl;
+        if (tv >= TV) { tv -= TV; ++bl; }
+    }
+};
+
 // Block reduction of NV doubles (sum); result valid in thread 0.
 template <int NV>
 __device__ void block_sum(double (&v)[NV], double* sh) {
@@ -212,10 +227,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
     double acc[2] = {0, 0};
     float s0 = 0.f, s1 = 0.f;
-    const long nloc = (long)(b1 - b0) * TV;
-    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
-        const int bl = (int)(e / TV);
-        const int tv = (int)(e - (long)bl * TV);
+    const int nb = b1 - b0;
+    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
+        const int bl = w.bl, tv = w.tv;
         const long off = ((long)(b0 + bl) * C + c) * T + (long)tv * VEC;
         const Pack<VEC> d = Pack<VEC>::ld(dout + off), v = Pack<VEC>::ld(y + off);
 #pragma unroll
@@ -268,10 +282,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         }
     }
     float sdy = 0.f;
-    const long nloc = (long)(b1 - b0) * TV;
-    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
-        const int bl = (int)(e / TV);
-        const int tv = (int)(e - (long)bl * TV);
+    const int nb = b1 - b0;
+    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
+        const int bl = w.bl, tv = w.tv;
         const long off = ((long)(b0 + bl) * C + c) * T + (long)tv * VEC;
         const Pack<VEC> d = Pack<VEC>::ld(dout + off), v = Pack<VEC>::ld(y + off);
         Pack<VEC> o;
@@ -304,6 +317,16 @@ __global__ void finalize_channel_sums_kernel(const double* __restrict__ partial,
 }
 
 extern "C" int bm_bwd_nsplit(int B) { return B >= 64 ? 8 : (B >= 8 ? 4 : 1); }
+
+// BM_GELU_GRAD_ERF=1: the GELU derivative through erff + expf (A/B switch; default = bm_gelu_grad_fast)
+static int gelu_grad_code(int act) {
+    static int erf_form = -1;
+    if (erf_form < 0) {
+        const char* e = getenv("BM_GELU_GRAD_ERF");
+        erf_form = (e && e[0] == '1');
+    }
+    return (act == BM_ACT_GELU && !erf_form) ? BM_ACT_GELU_FASTGRAD : act;
+}
 
 // BM_BN_APPLY_REVERSE=0: the apply pass walks the batch in the same order as the reduce pass (A/B switch)
 static int bn_apply_reverse() {
@@ -340,6 +363,7 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     const dim3 grid(C, nsplit);
     const bool reduce = bn_train || (scale && (dgamma || dbeta));
+    act = gelu_grad_code(act);
     if (T % 4 == 0) {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
@@ -381,10 +405,9 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
     float s = 0.f;
-    const long nloc = (long)(b1 - b0) * TV;
-    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
-        const int bl = (int)(e / TV);
-        const int tv = (int)(e - (long)bl * TV);
+    const int nb = b1 - b0;
+    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
+        const int bl = w.bl, tv = w.tv;
         const Pack<VEC> v = Pack<VEC>::ld(x + (long)(b0 + bl) * bstride + (long)c * T + (long)tv * VEC);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s += v.v[i];
@@ -457,10 +480,9 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
     float s = 0.f, s2 = 0.f;
-    const long nloc = (long)(b1 - b0) * TV;
-    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
-        const int bl = (int)(e / TV);
-        const int tv = (int)(e - (long)bl * TV);
+    const int nb = b1 - b0;
+    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
+        const int bl = w.bl, tv = w.tv;
         const Pack<VEC> v = Pack<VEC>::ld(x + ((long)(b0 + bl) * C + c) * T + (long)tv * VEC);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { s += v.v[i]; s2 += v.v[i] * v.v[i]; }
@@ -549,10 +571,9 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
     const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
     const int TV = T / VEC;
     float sa = 0.f, sg = 0.f;
-    const long nloc = (long)(b1 - b0) * TV;
-    for (long e = threadIdx.x; e < nloc; e += blockDim.x) {
-        const int bl = (int)(e / TV);
-        const int tv = (int)(e - (long)bl * TV);
+    const int nb = b1 - b0;
+    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
+        const int bl = w.bl, tv = w.tv;
         const int b = b0 + bl;
         const long offo = ((long)b * H + hch) * T + (long)tv * VEC;
         const long offa = ((long)b * 2 * H + hch) * T + (long)tv * VEC;

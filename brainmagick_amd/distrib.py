@@ -111,6 +111,14 @@ def _rendezvous_store(rank: int, world: int):
     """The TCP store of the torchrun / env:// rendezvous (the agent's store under torchrun, else rank 0
     hosts it on MASTER_ADDR:MASTER_PORT).  Host-side key/value plumbing only; one per process."""
     global _store_cache
+    if _store_cache is None and dist.is_available() and dist.is_initialized():
+        # somebody already ran the env:// rendezvous in this process (outside torchrun rank 0 hosts the store on
+        # MASTER_PORT: a second TCPStore there would die with EADDRINUSE): ride on that group's store
+        try:
+            from torch.distributed.distributed_c10d import _get_default_store
+            _store_cache = dist.PrefixStore("bm_rdzv", _get_default_store())
+        except Exception:                   # no accessible default store: fall through to our own
+            _store_cache = None
     if _store_cache is None:
         host = os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(os.environ.get("MASTER_PORT", "29500"))
@@ -184,14 +192,24 @@ class _RcclComm:
         if not loaded:
             raise RcclUnavailable("librccl could not be loaded on at least one rank: " +
                                   (self._lib.bm_last_error() or b"").decode())
+        # the unique id: rank 0 creates and publishes it.  A failure there is published too (an empty value), so that
+        # the other ranks fall back with rank 0 instead of sitting in store.get() until the store times out
         if self.rank == 0:
-            buf = ctypes.create_string_buffer(nbytes)
-            check(self._lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
-            uid = buf.raw
+            uid, err = b"", ""
+            try:
+                buf = ctypes.create_string_buffer(nbytes)
+                check(self._lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
+                uid = buf.raw
+            except Exception as exc:            # noqa: BLE001 -- reported to every rank through the store
+                err = str(exc)
             if self._store is not None:
                 self._store.set(key + "/id", uid)
+            if not uid:
+                raise RcclUnavailable(f"bm_comm_unique_id failed on rank 0: {err}")
         else:
             uid = bytes(self._store.get(key + "/id"))
+            if not uid:
+                raise RcclUnavailable("bm_comm_unique_id failed on rank 0")
         # phase 2: the communicator itself; the outcome is agreed again so that a rank whose init failed does
         # not leave the others with a communicator nobody else joins
         handle = ctypes.c_void_p()
@@ -336,10 +354,13 @@ def init(backend: tp.Optional[str] = None):
 
 
 def shutdown():
-    global _comm
+    """Tear the communicator down; a later ``init()`` (another MASTER_PORT / WORLD_SIZE in the same process) starts
+    from a fresh rendezvous store."""
+    global _comm, _store_cache
     if _comm is not None:
         _comm.close()
         _comm = None
+    _store_cache = None
 
 
 def barrier():
@@ -389,6 +410,11 @@ def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None, shard: 
     if not is_distributed():
         optimizer.step()
         return
+    # after zero_grad(set_to_none=True) the bucket is only complete once the gradients autograd handed over have
+    # been moved into it: never communicate a partly fresh bucket (no-op when the caller did it already)
+    collect = getattr(optimizer, "collect_grads", None)
+    if collect is not None:
+        collect()
     if shard is None:
         shard = _SHARD_DEFAULT
     if shard:
@@ -482,51 +508,73 @@ class CandidateGather:
     """Whole-node negatives: all-gather of the candidate features, overlapped with the forward.
 
     ``start(candidates)`` enqueues the all-gather on a side stream; ``wait()`` returns
-    ``(gathered [world*B, ...] in rank order, target_offset = rank*B)``.  Every rank must bring the
-    same number of segments (the Solver refuses the configurations in which per-rank rejection
-    could break that, and ``BM_CHECK_RANKS=1`` verifies it with an extra tiny all-reduce)."""
+    ``(gathered [world*B, ...] in rank order, target_offset = rank*B, valid | None)``.
+
+    Ranks normally bring the same number of segments (``BM_CHECK_RANKS=1`` verifies it with an extra tiny
+    all-reduce).  When per-rank rejection can break that (``ScaleReject`` without clipping, bm/norm.py:335-343), the
+    Solver passes ``block_rows`` = the nominal per-rank batch size: a rank's ``n <= block_rows`` candidates are
+    zero-padded to the block, the counts travel with a second (one float per rank) all-gather on the same stream,
+    and ``valid`` ([world*block_rows] fp32, 1 = real candidate) masks the padding rows in ClipLoss -- all on the
+    device, no host synchronisation."""
 
     def __init__(self):
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._out = None
         self._B = 0
+        self._valid = None
 
-    def start(self, candidates: torch.Tensor):
+    def start(self, candidates: torch.Tensor, block_rows: tp.Optional[int] = None):
+        self._valid = None
         if not is_distributed():
             self._out = candidates
             return
         world = world_size()
-        self._B = candidates.shape[0]
+        n = candidates.shape[0]
+        self._B = n if block_rows is None else block_rows
+        assert n <= self._B, (n, self._B)
         if os.environ.get("BM_CHECK_RANKS", "0") == "1":
-            check_equal_over_ranks(candidates.numel(), "candidate block size")
+            check_equal_over_ranks(self._B * (candidates.numel() // max(n, 1)), "candidate block size")
         candidates = candidates.contiguous()
-        out = torch.empty((world * self._B,) + tuple(candidates.shape[1:]), device=candidates.device,
-                          dtype=candidates.dtype)
-        if self.stream is not None and candidates.is_cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                _comm.all_gather(out, candidates)
-            candidates.record_stream(self.stream)
-            out.record_stream(self.stream)
-        else:
-            _comm.all_gather(out, candidates)
+        side = self.stream if (self.stream is not None and candidates.is_cuda) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            out = torch.empty((world * self._B,) + tuple(candidates.shape[1:]), device=candidates.device,
+                              dtype=candidates.dtype)
+            send = candidates
+            if block_rows is not None:
+                if n < self._B:
+                    send = candidates.new_zeros((self._B,) + tuple(candidates.shape[1:]))
+                    send[:n].copy_(candidates)
+                counts = torch.empty(world, device=candidates.device, dtype=torch.float32)
+                _comm.all_gather(counts, torch.full((1,), float(n), device=candidates.device, dtype=torch.float32))
+                rows = torch.arange(self._B, device=candidates.device, dtype=torch.float32)
+                self._valid = (rows[None, :] < counts[:, None]).to(torch.float32).reshape(-1).contiguous()
+            _comm.all_gather(out, send)
+        if side is not None:
+            candidates.record_stream(side)
+            cur = torch.cuda.current_stream()
+            out.record_stream(cur)                  # allocated under the side stream, consumed on this one
+            if self._valid is not None:
+                self._valid.record_stream(cur)
         self._out = out
 
     def cancel(self):
         """Drop a gather that was started for a batch nobody will train on (the collective itself still runs to
         completion on the side stream: every rank issued it)."""
         self._out = None
+        self._valid = None
 
-    def wait(self) -> tp.Tuple[torch.Tensor, int]:
-        out = self._out
-        self._out = None
+    def wait(self) -> tp.Tuple[torch.Tensor, int, tp.Optional[torch.Tensor]]:
+        out, valid = self._out, self._valid
+        self._out = self._valid = None
         if out is None:
             raise RuntimeError("CandidateGather.wait() without a matching start()")
         if not is_distributed():
-            return out, 0
+            return out, 0, None
         if self.stream is not None and out.is_cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
-        return out, rank() * self._B
+        return out, rank() * self._B, valid
 
 
 class GatherCandidatesFn(torch.autograd.Function):

@@ -28,9 +28,15 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 def _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight):
     """dW in the layout of the parameter: Conv1d [M,Cin,KS] or ConvTranspose1d(k=1) [Cin,M,1]; written straight into
     the optimizer's flat gradient bucket when the parameter has a registered destination (hip_ops.grad_destination)."""
+    dst = H.grad_destination(weight)
+    # the contraction shares nothing but its inputs with the data gradient that follows: second stream (hip_ops)
+    with H.side_stream_of_backward(dy, x, dst):
+        return _conv_weight_grads_here(dy, x, weight, KS, dil, transposed_weight, dst)
+
+
+def _conv_weight_grads_here(dy, x, weight, KS, dil, transposed_weight, dst):
     B, M, T = dy.shape
     Cin = x.shape[1]
-    dst = H.grad_destination(weight)
     # (a registered destination is returned as a FRESH view: autograd only adopts a gradient tensor nobody else holds)
     if transposed_weight:
         out = dst if dst is not None else torch.empty(weight.shape, device=dy.device, dtype=torch.float32)   # [Cin, M, 1]
@@ -83,6 +89,10 @@ class Conv1dFn(torch.autograd.Function):
             dy = dout
             if has_bias:
                 dbias = H.channel_sum(dy)
+        # (the weight gradient first: it is handed to the side stream at this point of the current one, and the data
+        # gradient enqueued behind it then runs NEXT TO it)
+        dw = _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight) \
+            if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
             if transposed_weight:
@@ -92,8 +102,6 @@ class Conv1dFn(torch.autograd.Function):
                 M, Cin, _ = weight.shape
                 wp = H.pack_conv_dgrad(weight, (dy.shape[2], dil))
             _, dx, _ = H.conv_nn(dy, wp, Cin, KS, dil)
-        dw = _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight) \
-            if ctx.needs_input_grad[1] else None
         return dx, dw, dbias, None, None, None, None
 
 
@@ -142,12 +150,12 @@ class ConvBNActFn(torch.autograd.Function):
         M, Cin, _ = weight.shape
         dy, dgamma, dbeta, dbias = H.act_bn_bwd(dout, pre, scale, shift, mean, invstd, training, act,
                                                 leak, want_affine_grads=True, want_dbias=has_bias)
+        dw = _conv_weight_grads(dy, x, weight, KS, dil, False) if ctx.needs_input_grad[1] else None   # side stream
         dx = None
         if ctx.needs_input_grad[0]:
             # dx feeds the previous layer's elementwise backward kernel: nobody needs its maximum
             _, dx, _ = H.conv_nn(dy, H.pack_conv_dgrad(weight, (dy.shape[2], dil)), Cin, KS, dil,
                                  res=dout if residual else None, publish_amax=False)
-        dw = _conv_weight_grads(dy, x, weight, KS, dil, False) if ctx.needs_input_grad[1] else None
         return (dx, dw, dbias, dgamma, dbeta) + (None,) * 10
 
 
@@ -170,10 +178,10 @@ class GLUConvFn(torch.autograd.Function):
         x, weight, u = ctx.saved_tensors
         M, Cin, KS = weight.shape
         du, dbias = H.glu_bwd(_c(dout), u, want_dbias=ctx.has_bias)
+        dw = _conv_weight_grads(du, x, weight, KS, 1, False) if ctx.needs_input_grad[1] else None     # side stream
         dx = None
         if ctx.needs_input_grad[0]:
             _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight, (du.shape[2], 1)), Cin, KS, 1, publish_amax=False)
-        dw = _conv_weight_grads(du, x, weight, KS, 1, False) if ctx.needs_input_grad[1] else None
         return dx, dw, dbias
 
 
@@ -381,7 +389,7 @@ class ClipLossFn(torch.autograd.Function):
     MFMA GEMM dEst = dScores . cand."""
 
     @staticmethod
-    def forward(ctx, estimate, candidate, target_offset: int = 0):
+    def forward(ctx, estimate, candidate, target_offset: int = 0, col_valid=None):
         estimate, candidate = _c(estimate), _c(candidate)
         B, Bc = estimate.shape[0], candidate.shape[0]
         K = estimate.numel() // B
@@ -389,7 +397,7 @@ class ClipLossFn(torch.autograd.Function):
         inv = H.clip_inv_norms(candidate)
         part = _clip_raw_scores(estimate, candidate, B, Bc, K)
         scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True,
-                                             target_offset=target_offset)
+                                             target_offset=target_offset, col_valid=col_valid)
         if ctx.needs_input_grad[1]:
             ctx.save_for_backward(candidate, dscaled, estimate, scores, inv)
         else:
@@ -429,7 +437,7 @@ class ClipLossFn(torch.autograd.Function):
             coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
             H.row_axpy_sub(dcand, cand2, coef)
             dcand = dcand.view(ctx.cand_shape)
-        return dest, dcand, None
+        return dest, dcand, None, None
 
 
 def clip_scores(estimate, candidate, want_probs=False):

@@ -27,6 +27,7 @@ BKC = 16
 #   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
 #   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
 import os as _os
+import threading as _threading
 DEFAULT_COMPUTE_DTYPE = "f16x2"
 COMPUTE_DTYPES = ("f32", "f32x3", "f16x2", "bf16")
 _compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE)
@@ -215,6 +216,8 @@ def _touched(t: torch.Tensor) -> torch.Tensor:
 def share_amax(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
     """``view`` is a slice of ``src``: the maximum of the whole tensor bounds the slice (any upper bound within the
     f16 headroom serves as the scale), so the slice needs no pass of its own."""
+    if _compute_dtype != "f16x2":     # nobody consumes a maximum in the other compute modes: no scan
+        return view
     slot = amax(src)
     try:
         view._bm_amax = (view._version, view.data_ptr(), slot, False)
@@ -449,7 +452,7 @@ def raise_if_index_error(device=None):
     flags = list(_index_err.values()) if device is None else [index_error_flag(device)]
     for flag in flags:
         if int(flag[0].item()) != 0:
-            flag.zero_()
+            flag[0:1].zero_()       # (the other two words -- non-finite input, bad mask -- belong to the Solver)
             raise IndexError("subject / layout index out of range for the weight table "
                              "(bm/models/common.py:57 would raise in `weights.gather`)")
 
@@ -551,13 +554,119 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# Side stream of the backward pass.  The weight gradient of a conv layer and its data gradient both consume dy and
+# nothing else links them, so the weight-gradient contraction (and its split fold) is enqueued on a second HIP
+# stream: the two MFMA kernels share the chip, their tiles fall out of step, and one kernel's store drains /
+# prologues (19 % / 10 % of a tile with the matrix pipe idle) run under the other's main loops;
+# the chains of small latency-bound launches at both ends of the backward pass overlap with weight gradients too.
+# Ordering: the side stream waits for the current stream when a contraction is handed over (dy and its maxima are
+# complete), the current stream waits for the side stream when the autograd engine finishes the backward pass (engine
+# callback: `loss.backward()` returns with every gradient ordered on the caller's stream, whoever the caller is --
+# Solver, the reference's solver loop, or a test).  BM_WGRAD_STREAM=0: everything on one stream (A/B switch).
+_WGRAD_STREAM = _os.environ.get("BM_WGRAD_STREAM", "1") == "1"
+_WGRAD_STREAM_PRIORITY = int(_os.environ.get("BM_WGRAD_STREAM_PRIORITY", "0"))   # 0 = like the main stream; A/B knob
+_side_streams: tp.Dict[tp.Tuple[int, int, int], tuple] = {}    # (device, stream, thread) -> (that stream, its side stream)
+_side_pending: tp.Dict[tp.Tuple[int, int, int], bool] = {}                 # ... -> a join is owed (callback queued)
+side_stream_launches = 0     # contractions handed to a side stream (tests / bench bookkeeping)
+
+
+def set_wgrad_stream(on: bool):
+    """Switch the weight-gradient side stream on / off at run time (bench.py measures both)."""
+    global _WGRAD_STREAM
+    join_side_streams()
+    _WGRAD_STREAM = bool(on)
+
+
+def _join_side_stream(key):
+    if _side_pending.get(key):
+        cur, side = _side_streams[key]
+        cur.wait_stream(side)
+        _side_pending[key] = False
+
+
+def join_side_streams():
+    """Every stream that handed work to a side stream waits for it (idempotent, no host sync)."""
+    for key in list(_side_pending):
+        _join_side_stream(key)
+
+
+class side_stream_of_backward:
+    """``with side_stream_of_backward(tensors...) as on:`` -- inside a backward function: runs the body on the side
+    stream of the current (device, stream) when the switch is on (``on`` tells), after making it wait for the current
+    stream; the tensors named are protected from re-use by the caching allocator until the side stream is done with
+    them (record_stream); the join is queued on the autograd engine's completion callback once per backward pass."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if not _WGRAD_STREAM or not self.tensors:
+            return False
+        dev = self.tensors[0].device
+        cur = torch.cuda.current_stream(dev)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), cur.cuda_stream,
+               _threading.get_ident())
+        if key not in _side_streams:
+            _side_streams[key] = (cur, torch.cuda.Stream(device=dev, priority=_WGRAD_STREAM_PRIORITY))
+        side = _side_streams[key][1]
+        if not _side_pending.get(key):
+            try:
+                # (the engine runs the callback on whichever thread completes the graph task: the closure names the
+                # stream pair, not "the current stream")
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side_stream(key))
+            except RuntimeError:
+                return False            # not inside a backward pass (a direct call of the function): stay on this stream
+            _side_pending[key] = True
+        side.wait_stream(cur)
+        for t in self.tensors:
+            t.record_stream(side)
+        global side_stream_launches
+        side_stream_launches += 1
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+class _DirectArmed:
+    """(a plain counter, not thread-local: the autograd engine runs the backward nodes on its own worker thread)"""
+    depth = 0
+
+    @property
+    def on(self):
+        return self.depth > 0
+
+
+_direct_armed = _DirectArmed()
+
+
+class direct_grads_armed:
+    """Context in which ``grad_destination`` hands out the flat-bucket views (``FlatAdam.writing_grads``): the
+    backward pass of the training step, and nothing else -- gradients returned by ``torch.autograd.grad`` or produced
+    by a stray backward must not alias the optimizer's bucket."""
+
+    def __enter__(self):
+        _direct_armed.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        _direct_armed.depth -= 1
+        return False
+
+
 def grad_destination(param: torch.Tensor) -> tp.Optional[torch.Tensor]:
     """Where the weight gradient of ``param`` may be written directly: its view of the optimizer's flat gradient bucket
     (``FlatAdam`` registers it as ``param._bm_grad_dst``), handed out ONCE per ``zero_grad`` -- a parameter that
     takes part in the graph twice gets a fresh tensor the second time, and autograd accumulates as usual.  The
     returned view becomes ``param.grad`` without a copy (``FlatAdam.collect_grads`` recognises the address)."""
     dst = getattr(param, "_bm_grad_dst", None)
-    if dst is None or dst[1][0] or param.grad is not None or not _DIRECT_GRADS:
+    if dst is None or dst[1][0] or param.grad is not None or not _DIRECT_GRADS or not _direct_armed.on:
         return None
     dst[1][0] = True
     return dst[0]
@@ -794,8 +903,9 @@ def flag_unless_all_set(mask: torch.Tensor, flag: torch.Tensor) -> None:
 
 
 def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
-            target_offset: int = 0):
-    """part [nsplit][B][B'] -> (scores, probs|None, dscaled|None, loss|None)."""
+            target_offset: int = 0, col_valid: tp.Optional[torch.Tensor] = None):
+    """part [nsplit][B][B'] -> (scores, probs|None, dscaled|None, loss|None).  ``col_valid`` ([B'] fp32, optional):
+    candidates with 0 there are masked out of every row (score -inf, probability 0, gradient 0)."""
     _req(part, "clip_ce.part")
     nsplit, B, Bc = part.shape
     dev = part.device
@@ -804,8 +914,9 @@ def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
     dscaled = torch.empty(B, Bc, device=dev, dtype=torch.float32) if want_grad else None
     loss_row = torch.empty(B, device=dev, dtype=torch.float32) if want_loss else None
     loss = torch.empty((), device=dev, dtype=torch.float32) if want_loss else None
-    check(lib().bm_clip_ce(_p(part), nsplit, _p(_req(inv_norm, "inv_norm")), _p(scores), _p(probs),
-                           _p(dscaled), _p(loss_row), _p(loss), B, Bc, target_offset, _stream()), "bm_clip_ce")
+    check(lib().bm_clip_ce_masked(_p(part), nsplit, _p(_req(inv_norm, "inv_norm")), _p(_opt(col_valid, "col_valid")),
+                                  _p(scores), _p(probs), _p(dscaled), _p(loss_row), _p(loss), B, Bc, target_offset,
+                                  _stream()), "bm_clip_ce")
     return scores, probs, dscaled, loss
 
 

@@ -78,11 +78,13 @@ class ClipLoss(torch.nn.Module):
         estimates, candidates = self._prepare(estimates, candidates)
         return BF.clip_scores(estimates.detach(), candidates.detach(), want_probs=True)
 
-    def forward(self, estimate, candidate, mask=None, target_offset: int = 0):
+    def forward(self, estimate, candidate, mask=None, target_offset: int = 0, candidate_valid=None):
         """The first B candidates are the targets of the B estimates, the remaining B'-B are only
         negatives (losses.py:104-114).  ``target_offset`` (extension, default 0 = reference
         behaviour) shifts the targets to candidates [offset, offset+B): a data-parallel rank uses
-        it to point at its own block of the whole-node gathered candidates."""
+        it to point at its own block of the whole-node gathered candidates.  ``candidate_valid``
+        (extension, [B'] fp32, default None = all): candidates marked 0 are padding (ranks that rejected
+        different numbers of segments bring equal-sized, partly empty blocks) and never count as negatives."""
         if self.defer_mask_check and mask.is_cuda and mask.dtype == torch.bool:
             # Solver: the reference's assert costs a host sync in the middle of the step; the verdict is OR-ed into
             # the device-side flag word and raised at the next step's single synchronisation point
@@ -94,4 +96,4 @@ class ClipLoss(torch.nn.Module):
         assert estimate.size(0) + target_offset <= candidate.size(0), \
             "need at least as many targets as estimates"
         estimate, candidate = self._prepare(estimate, candidate)
-        return BF.ClipLossFn.apply(estimate, candidate, target_offset)[0]
+        return BF.ClipLossFn.apply(estimate, candidate, target_offset, candidate_valid)[0]

@@ -105,6 +105,14 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_grad.zero_()
         self._attach_views()
 
+    def writing_grads(self):
+        """``with optimizer.writing_grads(): loss.backward()`` -- inside, the weight-gradient kernels may write a
+        parameter's gradient straight into its slice of the flat bucket (after ``zero_grad(set_to_none=True)``; the
+        tensor autograd then stores in ``p.grad`` IS the bucket view, ``collect_grads`` has nothing to copy).  Outside
+        such a block (``torch.autograd.grad`` for analysis, a backward pass of some other loss) gradients are fresh
+        tensors that alias nothing."""
+        return H.direct_grads_armed()
+
     def _attach_views(self):
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:

@@ -25,7 +25,8 @@ class Solver:
                  optimizer: tp.Optional[FlatAdam] = None, device: str = "cuda",
                  offset_meg_ms: float = 0., sample_rate: float = 120., negatives: str = "local",
                  lr: float = 3e-4, betas=(0.9, 0.999), scale_reject=None,
-                 feature_model: tp.Optional[torch.nn.Module] = None, check_finite: bool = True):
+                 feature_model: tp.Optional[torch.nn.Module] = None, check_finite: bool = True,
+                 n_negatives: tp.Optional[int] = None, negative_pool_size: tp.Optional[int] = None):
         assert negatives in ("local", "node")
         self.device = torch.device(device)
         self.model = model.to(self.device)
@@ -43,26 +44,86 @@ class Solver:
         self.negatives = negatives
         self._gather = distrib.CandidateGather() if negatives == "node" else None
         self.scale_reject = scale_reject          # brainmagick_amd.norm.ScaleReject or None
-        if negatives == "node" and scale_reject is not None and \
-                (not scale_reject.clip or scale_reject.exclude_empty_features):
-            # per-rank rejection would leave ranks with different numbers of segments: the candidate
-            # all-gather (equal blocks, target_offset = rank * B) cannot express that
-            raise ValueError('negatives="node" needs the same number of segments on every rank: use '
-                             'ScaleReject(clip=True, exclude_empty_features=False) (conf/config.yaml:131 '
-                             'norm.clip=true) or negatives="local"')
+        # Per-rank rejection (ScaleReject(clip=False) / exclude_empty_features) leaves ranks with different numbers
+        # of segments.  Whole-node negatives then gather equal-sized blocks of the NOMINAL batch size, the rows a rank
+        # rejected are padding, and ClipLoss masks them (candidate_valid) -- decided from the configuration, so every
+        # rank takes the same branch.
+        self._ragged_node = negatives == "node" and scale_reject is not None and \
+            (not scale_reject.clip or scale_reject.exclude_empty_features)
+        if self._ragged_node and feature_model is not None:
+            raise ValueError('negatives="node" with a learnable feature model needs the same number of segments on '
+                             'every rank: use ScaleReject(clip=True, exclude_empty_features=False) or negatives="local"')
+        # bm/solver.py:153-165,358-371: `optim.negatives` -- candidates completed with random draws from a pool of
+        # the previous batches' candidates (kept on the device here; the reference keeps it on the CPU)
+        self.n_negatives = n_negatives
+        if n_negatives is not None:
+            if negatives == "node":
+                raise ValueError('n_negatives (bm optim.negatives) completes the LOCAL candidates from a pool; '
+                                 'it does not combine with negatives="node"')
+            if negative_pool_size is None:
+                negative_pool_size = 2 * n_negatives                    # bm/solver.py:155-157
+            assert negative_pool_size >= n_negatives, "Pool of negatives should be larger than the number of negatives"
+        self.negative_pool_size = negative_pool_size
+        self.negative_pool: tp.Dict[str, tp.Optional[torch.Tensor]] = {"train": None, "valid": None}
+        self.negative_generator: tp.Optional[torch.Generator] = None    # CPU generator of the pool draws (tests seed it)
         # flashy.distrib.sync_model also averages the float buffers (BatchNorm running statistics)
         self._buffers = distrib.BufferBucket(self._all_models())
         self.check_finite = check_finite          # bm/solver.py:258-260 asserts (one fused host sync)
         self.loss.defer_mask_check = check_finite  # bm/losses.py:110 assert: same sync point, one step late
         self._last_batch = None
         self._prefetched = None
+        self._staged: tp.Dict[int, tuple] = {}    # id(host batch) -> (host batch, device batch): see stage()
+        self._copy_stream = None
+        self._substituted = False
+
+    # -- bm/solver.py:243 `batch.to(self.device)` ----------------------------------------------------
+    def stage(self, batch):
+        """Host -> device copy of a batch on a dedicated copy stream, without blocking the host when the host
+        tensors are pinned (``SegmentBatch.pin()``, or a DataLoader with ``pin_memory=True``): 121 MB per step at
+        cfg2 travel next to the previous step's kernels instead of in front of this step's (the reference's
+        ``batch.to(device)`` is a blocking pageable copy, bm/solver.py:243).  ``train_step(batch, next_batch=...)``
+        stages ``next_batch`` before it enqueues anything of the current step; a batch that is already on the device
+        passes through.  The compute stream waits for the copy when the batch is consumed (``_prepare``)."""
+        if not isinstance(getattr(batch, "meg", None), torch.Tensor) or batch.meg.device == self.device:
+            return batch
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._copy_stream):
+            try:
+                dev = batch.to(self.device, non_blocking=True)
+            except TypeError:                       # the reference's SegmentBatch.to(device) has no such argument
+                dev = batch.to(self.device)
+        if len(self._staged) >= 4:                  # batches staged and never consumed
+            self._staged.clear()
+        self._staged[id(batch)] = (batch, dev)
+        return dev
+
+    def _on_device(self, batch):
+        staged = self._staged.pop(id(batch), None)
+        if staged is not None and staged[0] is batch:
+            dev = staged[1]
+        else:
+            dev = self.stage(batch)
+            if dev is batch:
+                return batch
+            self._staged.pop(id(batch), None)
+        # the copies were enqueued on the copy stream: order them in front of the consumers, and keep the allocator
+        # from recycling the blocks while the compute stream still reads them
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self._copy_stream)
+        for name in ("meg", "features", "features_mask", "subject_index", "recording_index"):
+            t = getattr(dev, name, None)
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
+        return dev
 
     # -- bm/solver.py:230-321 ------------------------------------------------------------------
     def _prepare(self, batch):
         """Everything of ``_process_batch`` in front of the model: device copy, scale / clamp / reject, the
         finiteness asserts, offset slicing -- and, with whole-node negatives and constant candidates, the start of
         the candidate all-gather (candidates are inputs: the exchange runs next to the encoder)."""
-        batch = batch.to(self.device)
+        nominal = len(batch.meg)                   # segments before rejection: the block size of the candidate gather
+        batch = self._on_device(batch)
         if self.scale_reject:
             batch, reject_mask = self.scale_reject(batch)          # bm/solver.py:245-246
         else:
@@ -93,27 +154,36 @@ class Solver:
         features = features.contiguous()
         if self._gather is not None and self.feature_model is None:
             # candidates do not depend on the model: start the xGMI all-gather before the encoder
-            self._gather.start(features)
+            self._gather.start(features, block_rows=nominal if self._ragged_node else None)
         return batch, meg.contiguous(), features, features_mask, reject_mask
 
     def prefetch(self, next_batch) -> None:
         """Optional: hand over the batch of the NEXT step (``train_step(batch, next_batch=...)`` calls this between
-        the loss and the backward pass).  Its preparation (device copy, scaling, the max|x| / finiteness pass) is
-        enqueued now and -- the point -- with whole-node negatives its candidate all-gather (3 GB at 8 x 256
-        wav2vec2-sized candidates, ~10 ms on xGMI against a ~5 ms forward) runs on the side stream NEXT TO THIS STEP'S
-        BACKWARD instead of in front of the next forward.  Nothing here synchronises the host (the asserts of the
-        prepared batch are read when it is consumed).  The next ``train_step`` / ``_process_batch`` recognises the
-        batch by identity.  Every rank must prefetch (or not) alike."""
+        the loss and the backward pass).  Its preparation (scaling, the max|x| / finiteness pass; the device copy was
+        staged at the start of the step) is enqueued now and -- the point -- with whole-node negatives its candidate
+        all-gather (3 GB at 8 x 256 wav2vec2-sized candidates, ~10 ms on xGMI against a ~5 ms forward) runs on the
+        side stream NEXT TO THIS STEP'S BACKWARD instead of in front of the next forward.  The host is not
+        synchronised here unless a ``ScaleReject`` that can reject has to count its rejections (bm/norm.py:341, one
+        small read-back); the asserts of the prepared batch are read when it is consumed.  The next ``train_step`` /
+        ``_process_batch`` recognises the batch by identity.  Every rank must prefetch (or not) alike."""
         if next_batch is None:
             self._prefetched = None
             return
-        self._prefetched = (next_batch, self._prepare(next_batch))
+        prepared = self._prepare(next_batch)
+        if prepared is None and self._gather is not None and self.feature_model is None and \
+                self._last_batch is not None:
+            # fully rejected: the step will re-run the last good batch (bm/solver.py:345-352).  Prepare THAT now, so
+            # that this rank issues its candidate all-gather at the same place in the collective sequence as the others
+            prepared = self._prepare(self._last_batch)
+            self._prefetched = (next_batch, prepared, self._last_batch)
+            return
+        self._prefetched = (next_batch, prepared, next_batch)
 
     def _check_flags(self):
         """The ONE host synchronisation of a step: the device-side flag word holds "non-finite input"
         (bm/solver.py:258-260), "ClipLoss mask not all-true" (bm/losses.py:110) and "subject / layout index out of
         range" (the reference's `weights.gather` would have raised, bm/models/common.py:57) -- the last two raised by
-        the PREVIOUS step."""
+        the PREVIOUS step (``check_pending_flags()`` reads them without waiting for a next one)."""
         if not self.check_finite:
             return
         flag = H.index_error_flag(self.device)
@@ -127,11 +197,20 @@ class Solver:
         if index_err:
             H.raise_if_index_error(self.device)
 
+    def check_pending_flags(self) -> None:
+        """Raise what the LAST step left in the device-side flag word (mask not all-true, index out of range): call
+        it after the final ``train_step`` / at the end of an evaluation loop -- the deferred asserts of a step are
+        otherwise only read by the next one.  ``eval_step``, ``predict`` and ``state_dict`` call it."""
+        self._check_flags()
+
     def _process_batch(self, batch, training: bool = False):
         pre = self._prefetched
         self._prefetched = None
         if pre is not None and pre[0] is batch:
             prepared = pre[1]
+            if pre[2] is not batch:                       # fully rejected at prefetch time: the last good batch
+                batch = pre[2]                            # was prepared in its place (see prefetch)
+                self._substituted = True
         else:
             if pre is not None and self._gather is not None:
                 self._gather.cancel()                     # a prefetched gather nobody will consume
@@ -150,20 +229,43 @@ class Solver:
         return [self.model] + ([self.feature_model] if self.feature_model is not None else [])
 
     def _candidates(self, output):
-        """(candidates, target_offset): local, gathered on the side stream (constant candidates) or
-        gathered with an autograd-aware all-gather (learnable candidates)."""
+        """(candidates, target_offset, candidate_valid | None): local, gathered on the side stream (constant
+        candidates) or gathered with an autograd-aware all-gather (learnable candidates)."""
         if self.negatives != "node":
-            return output, 0
+            return output, 0, None
         if self.feature_model is None:
             return self._gather.wait()
-        return distrib.gather_learnable_candidates(output)
+        return distrib.gather_learnable_candidates(output) + (None,)
+
+    def _complete_with_pool(self, output, training: bool):
+        """bm/solver.py:358-371: with ``optim.negatives`` set, fewer candidates than that are completed with a random
+        draw from the pool of earlier candidates, and the pool takes the completed set in front."""
+        if self.n_negatives is None:
+            return output
+        with torch.no_grad():
+            if len(output) < self.n_negatives:
+                phase = "train" if training else "valid"
+                buf = self.negative_pool[phase]
+                if buf is None:
+                    buf = output.new_zeros((0,) + tuple(output.shape[1:]))
+                n_kept = self.n_negatives - len(output)
+                kept = torch.randperm(len(buf), generator=self.negative_generator)[:n_kept]
+                output = torch.cat([output, buf[kept.to(buf.device)]], dim=0)
+                buf = torch.cat([output.detach(), buf])
+                self.negative_pool[phase] = buf[:self.negative_pool_size]
+        return output
 
     # -- bm/solver.py:343-390 (one iteration) -----------------------------------------------------
     def train_step(self, batch, next_batch=None) -> torch.Tensor:
-        """One iteration.  ``next_batch`` (optional): see ``prefetch``."""
+        """One iteration.  ``next_batch`` (optional): the batch of the next step -- its host -> device copy is
+        staged right away on the copy stream (``stage``), the rest of its preparation and its candidate all-gather
+        are enqueued between the loss and the backward pass (``prefetch``)."""
+        if next_batch is not None:
+            self.stage(next_batch)
         for m in self._all_models():
             m.train(True)
         self.loss.train(True)
+        self._substituted = False
         estimate, output, features_mask, _ = self._process_batch(batch, training=True)
         if estimate is None:
             # bm/solver.py:345-352: a fully rejected batch re-uses the last good one so that every
@@ -171,16 +273,18 @@ class Solver:
             if self._last_batch is None:
                 raise RuntimeError("Empty batch and last batch is none")
             estimate, output, features_mask, _ = self._process_batch(self._last_batch, training=True)
-        else:
+        elif not self._substituted:
             self._last_batch = batch
-        output, target_offset = self._candidates(output)
-        loss = self.loss(estimate, output, features_mask, target_offset=target_offset)
+        output, target_offset, valid = self._candidates(output)
+        output = self._complete_with_pool(output, training=True)
+        loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid)
         if next_batch is not None:
             self.prefetch(next_batch)       # the next step's candidate all-gather runs next to this backward
         # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path
         # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        with self.optimizer.writing_grads():       # the weight-gradient kernels write straight into the flat bucket
+            loss.backward()
         self.optimizer.collect_grads()      # one multi-tensor copy instead of an accumulate-add per parameter
         distrib.sharded_step(self.optimizer, self._buffers)
         return loss.detach()
@@ -189,6 +293,7 @@ class Solver:
     def state_dict(self) -> dict:
         """COLLECTIVE in a data-parallel run (every rank calls it; rank 0 then saves): the Adam moments are sharded
         over the ranks and are gathered first -- ``FlatAdam.state_dict()`` itself never communicates."""
+        self.check_pending_flags()
         self.optimizer.gather_moments()
         out = {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
         if self.feature_model is not None:
@@ -208,8 +313,13 @@ class Solver:
             m.train(False)
         self.loss.train(False)
         estimate, output, features_mask, _ = self._process_batch(batch, training=False)
-        output, target_offset = self._candidates(output)
-        return self.loss(estimate, output, features_mask, target_offset=target_offset)
+        output, target_offset, valid = self._candidates(output)
+        output = self._complete_with_pool(output, training=False)
+        loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid)
+        # the mask assert of THIS call is deferred to the flag word: an evaluation loop has no next train_step that
+        # would read it (one small read-back per evaluation batch; the reference's assert synchronises as well)
+        self.check_pending_flags()
+        return loss
 
     @torch.no_grad()
     def predict(self, batch):
@@ -219,4 +329,5 @@ class Solver:
         estimate, output, _, _ = self._process_batch(batch, training=False)
         if self._gather is not None and self.feature_model is None:
             self._gather.wait()
+        self.check_pending_flags()
         return estimate, output

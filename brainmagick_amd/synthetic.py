@@ -54,11 +54,22 @@ class SegmentBatch:
     def __len__(self) -> int:
         return len(self.meg)
 
-    def to(self, device) -> "SegmentBatch":
+    def to(self, device, non_blocking: bool = False) -> "SegmentBatch":
+        """bm/dataset.py:259-266.  ``non_blocking`` (extension): asynchronous copies when the host tensors are pinned
+        (``pin()``), enqueued on the current stream -- ``Solver.stage`` runs them on its copy stream."""
         kw = {}
         for field in dataclasses.fields(self):
             data = getattr(self, field.name)
-            kw[field.name] = data.to(device) if isinstance(data, torch.Tensor) else data
+            kw[field.name] = data.to(device, non_blocking=non_blocking) if isinstance(data, torch.Tensor) else data
+        return SegmentBatch(**kw)
+
+    def pin(self) -> "SegmentBatch":
+        """The same batch with its host tensors in page-locked memory (what a DataLoader with ``pin_memory=True``
+        delivers): the precondition of an asynchronous host -> device copy."""
+        kw = {}
+        for field in dataclasses.fields(self):
+            data = getattr(self, field.name)
+            kw[field.name] = data.pin_memory() if isinstance(data, torch.Tensor) and not data.is_cuda else data
         return SegmentBatch(**kw)
 
     def replace(self, **kwargs) -> "SegmentBatch":

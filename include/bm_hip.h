@@ -242,6 +242,12 @@ int bm_flag_unless_all_set(const unsigned char* mask, long n, int* flag, void* s
 int bm_clip_ce(const float* part, int nsplit, const float* inv_norm, float* scores, float* probs,
                float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
                void* stream);
+/* The same with a column mask (col_valid [Bc] floats, nullable; 0 = the candidate is padding): a masked candidate gets
+ * score -inf, probability 0 and gradient 0.  Whole-node negatives when ranks rejected different numbers of segments
+ * (bm/solver.py:245-246 ScaleReject next to the candidate all-gather of brainmagick_amd.solver). */
+int bm_clip_ce_masked(const float* part, int nsplit, const float* inv_norm, const float* col_valid, float* scores,
+                      float* probs, float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
+                      void* stream);
 
 /* Gradient of ClipLoss w.r.t. the candidates (learnable feature model, bm/solver.py:304-320):
  * coef[o] = alpha * (sum_b dscaled[b,o]*scores[b,o]) / |cand_o| ;  y[r] -= coef[r] * x[r]. */

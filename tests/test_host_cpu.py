@@ -148,9 +148,15 @@ assert torch.allclose(opt.flat_param, ref.flat_param, rtol=1e-6, atol=1e-7), (op
 gather = distrib.CandidateGather()
 cand = torch.full((3, 2, 5), float(r))
 gather.start(cand)
-out, off = gather.wait()
-assert out.shape == (6, 2, 5) and off == 3 * r
+out, off, valid = gather.wait()
+assert out.shape == (6, 2, 5) and off == 3 * r and valid is None
 assert (out[off:off + 3] == r).all() and (out[3 * (1 - r):3 * (1 - r) + 3] == 1 - r).all()
+# ragged blocks (per-rank rejection): rank r brings 3 - r of nominally 3 candidates; padding rows are flagged invalid
+gather.start(torch.full((3 - r, 2, 5), float(r + 1)), block_rows=3)
+out, off, valid = gather.wait()
+assert out.shape == (6, 2, 5) and off == 3 * r
+assert valid.tolist() == [1., 1., 1., 1., 1., 0.], valid
+assert (out[:3] == 1).all() and (out[3:5] == 2).all() and (out[5] == 0).all()
 m = distrib.average_metrics({"loss": float(r + 1)}, count=r + 1)
 assert abs(m["loss"] - (1 * 1 + 2 * 2) / 3) < 1e-9
 # BN buffers are averaged
@@ -361,7 +367,8 @@ def test_pack_plan_refresh_and_eviction_logic(monkeypatch):
 def test_loopback_communicator_runs_the_data_parallel_exchange_in_process():
     """tests/loopback.py (N replicas as threads of one process, the stand-in for ranks on the 1-GPU test box) against
     the same expectations as the 2-process gloo test: sharded step == mean-gradient Adam, rank-ordered candidate
-    gather, buffer averaging, moment gather -- here at world 2 and 3, with and without optimizer sharding."""
+    gather (also with ragged, padded blocks), buffer averaging, moment gather -- here at world 2, 3, 4 and 8, with and
+    without optimizer sharding."""
     from loopback import run_replicas
     from brainmagick_amd import distrib
 
@@ -381,7 +388,7 @@ def test_loopback_communicator_runs_the_data_parallel_exchange_in_process():
             O.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi] * grad_scale, self.m[lo:hi], self.v[lo:hi],
                         self.t)
 
-    for world in (2, 3):
+    for world in (2, 3, 4, 8):
         for shard in (True, False):
             def body(r):
                 assert distrib.is_distributed() and distrib.world_size() == world and distrib.rank() == r
@@ -392,8 +399,17 @@ def test_loopback_communicator_runs_the_data_parallel_exchange_in_process():
                     distrib.sharded_step(opt, shard=shard)
                 gather = distrib.CandidateGather()
                 gather.start(torch.full((3, 2, 5), float(r)))
-                out, off = gather.wait()
-                assert off == 3 * r and all(bool((out[3 * k:3 * k + 3] == k).all()) for k in range(world))
+                out, off, valid = gather.wait()
+                assert off == 3 * r and valid is None
+                assert all(bool((out[3 * k:3 * k + 3] == k).all()) for k in range(world))
+                # ragged blocks: rank r brings 1 + r % 3 of nominally 3 candidates, the rest of its block is padding
+                gather.start(torch.full((1 + r % 3, 2, 5), float(r + 1)), block_rows=3)
+                out, off, valid = gather.wait()
+                assert off == 3 * r and out.shape[0] == 3 * world
+                for k in range(world):
+                    n = 1 + k % 3
+                    assert valid[3 * k:3 * k + 3].tolist() == [1.] * n + [0.] * (3 - n)
+                    assert bool((out[3 * k:3 * k + n] == k + 1).all()) and bool((out[3 * k + n:3 * k + 3] == 0).all())
                 bn = torch.nn.BatchNorm1d(4)
                 bn.running_mean.fill_(float(r))
                 bucket = distrib.BufferBucket([bn])
