@@ -90,21 +90,24 @@ def algorithmic_bytes_per_step(C, T, F, B, n_params, hidden=320, merger_ch=270) 
 
 
 def pmc_traffic(kernel_label: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected per MI355X_MICROARCH.md;
-    see profiles/*pmc_summary.json).  PMC counters cannot be sampled from inside this process."""
-    files = sorted((ROOT / "profiles").glob("*pmc_summary*.json"))
+    """(HBM bytes per launch, summary file, that summary's average launch duration in ms) of the dominant kernel from
+    the newest committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected
+    per MI355X_MICROARCH.md; see profiles/*pmc_summary.json).  PMC counters cannot be sampled from inside this
+    process; the caller compares the summary's launch duration with the one it has just measured and marks the
+    figure stale when the kernel has changed since the counters were collected."""
+    files = sorted((ROOT / "profiles").glob("*pmc_summary*.json"), key=lambda f: f.stat().st_mtime)
     if not files:
-        return None, None
+        return None, None, None
     data = json.loads(files[-1].read_text())
     prefix = kernel_label.rstrip(">").replace(" ", "")
     for name, rec in data.get("kernels", {}).items():
         if name.replace(" ", "").replace("void", "", 1).startswith(prefix):
-            return rec.get("hbm_bytes_per_launch_corrected"), files[-1].name
-    return None, files[-1].name
+            avg = rec.get("avg_ns")
+            return rec.get("hbm_bytes_per_launch_corrected"), files[-1].name, (avg * 1e-6 if avg else None)
+    return None, files[-1].name, None
 
 
-def cpu_baseline(seconds_budget=14.0):
+def cpu_baseline(seconds_budget=14.0, full_batch=True):
     """The CPU oracle (port of the reference path) on cfg1 = BASELINE.json configs[0] (fake-study shaped,
     batch 16), timed with 1 thread (bm/train.py:182) and with all host cores, bounded samples."""
     from oracle import bm_oracle as O
@@ -137,9 +140,31 @@ def cpu_baseline(seconds_budget=14.0):
         med = timed[len(timed) // 2]
         out[label] = dict(value=B / med, unit="segments/s", cores=n, median_step_ms=med * 1e3,
                           steps_timed=len(timed), first_loss=losses[0])
+    # the SAME configuration as `value` (cfg2, batch 256): 1 warm-up + 2 timed steps on `many` threads (~15 s each)
+    cfg2 = None
+    if full_batch:
+        try:
+            c2 = synthetic.CONFIGS["cfg2"]
+            sb2 = synthetic.make_config_batch("cfg2", seed=2036)
+            torch.manual_seed(0)
+            m2 = SimpleConv(in_channels={"meg": c2["C"]}, out_channels=c2["F"], hidden={"meg": 320},
+                            n_subjects=c2["S"], **CLIP_CONV)
+            torch.set_num_threads(many)
+            o2 = O.OracleModel({k: v.clone() for k, v in m2.state_dict().items()}, O.CLIP_CONV_CFG, 320, c2["F"])
+            pos2, t2 = sb2.positions(), []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                o2.train_step(sb2.meg, pos2, sb2.subject_index, sb2.features, ban)
+                t2.append(time.perf_counter() - t0)
+            med2 = sorted(t2[1:])[0]
+            cfg2 = dict(value=c2["B"] / med2, unit="segments/s", cores=many, step_s=med2, steps_timed=2,
+                        sample="cfg2 (C=208 T=360 F=120), batch 256 -- the configuration of `value` -- whole training "
+                               "step of the CPU oracle, best of 2 steps after 1 warm-up")
+        except Exception as exc:            # the cfg1 figure must survive (host memory, time-outs)
+            cfg2 = {"error": repr(exc)}
     torch.set_num_threads(prev)
     best = max(out.values(), key=lambda r: r["value"])
-    return dict(value=best["value"], unit="segments/s", cores=best["cores"], kind="port",
+    return dict(value=best["value"], unit="segments/s", cores=best["cores"], kind="port", cfg2_b256=cfg2,
                 sample=f"cfg1 (C=273 T=360 F=120, batch {B}), clip_conv model, whole training step "
                        f"(forward + ClipLoss + backward + Adam), torch CPU fp32, median of "
                        f"{best['steps_timed']} steps after 1 warm-up; CPU oracle = restatement of the reference "
@@ -287,6 +312,100 @@ def clip_roofline(dev, mode, reps=20):
     return out
 
 
+def retrieval_roofline(dev, mode, n_queries=2048, n_cand=10000, F=120, T=360, cpu_seconds=12.0):
+    """Throughput of the batched retrieval evaluation (second half of the metric): `builds_probs`
+    (scripts/run_eval_probs.py:267-307: probabilities of N' candidates for N predictions, in query blocks) +
+    the top-10 / label-match rule (:237-264) at 2 048 queries x 10 000 candidates (bm/wer.py:71-79 draws 10 000
+    negatives), HIP events around the whole evaluation.  Algorithmic bytes: the candidates once per query block, the
+    queries once, the probabilities written and read once.  Beside it the reference's per-segment loop
+    (bm/wer.py:91-116, restated in oracle.get_wer_loop) on a bounded sample of queries on the host cores."""
+    from brainmagick_amd import retrieval
+    from brainmagick_amd.losses import ClipLoss
+    K = F * T
+    g = torch.Generator(device="cpu").manual_seed(11)
+    cand = torch.empty(n_cand, F, T, device=dev)
+    for r0 in range(0, n_cand, 1000):
+        cand[r0:r0 + 1000] = torch.randn(min(1000, n_cand - r0), F, T, generator=g).to(dev)
+    est = torch.empty(n_queries, F, T, device=dev)
+    for r0 in range(0, n_queries, 1024):
+        est[r0:r0 + 1024] = torch.randn(min(1024, n_queries - r0), F, T, generator=g).to(dev)
+    # plant the targets so that top-10 is neither 0 nor 1: query i resembles candidate i
+    est += 0.08 * cand[:n_queries]
+    clip = ClipLoss().to(dev)
+    labels = torch.arange(n_cand)
+    block = 1024
+
+    def run():
+        probs = retrieval.builds_probs(clip, est, cand, batch_size=block)
+        return retrieval.get_accuracy_from_probs(probs, labels[:n_queries], labels, topk=10)
+
+    run()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    ev0.record()
+    for _ in range(reps):
+        top10 = run()
+    ev1.record()
+    torch.cuda.synchronize()
+    t = ev0.elapsed_time(ev1) / reps * 1e-3
+    nblocks = -(-n_queries // block)
+    nbytes = 4.0 * (nblocks * n_cand * K + n_queries * K + 2.0 * n_queries * n_cand)
+    flops = 2.0 * n_queries * n_cand * K
+    peak = MODE_PEAK_TFLOPS[mode]
+    out = {"queries": n_queries, "candidates": n_cand, "K": K, "query_block": block, "seconds": t,
+           "queries_per_s": n_queries / t, "top10": top10,
+           "achieved_gbs": nbytes / t / 1e9, "peak_gbs": PEAK_HBM_GBS, "hbm_frac": nbytes / t / 1e9 / PEAK_HBM_GBS,
+           "achieved_tflops": flops / t / 1e12, "peak_tflops": peak, "mfma_frac": flops / t / 1e12 / peak,
+           "algorithmic_bytes": nbytes}
+    out["bound"] = "mfma" if out["mfma_frac"] >= out["hbm_frac"] else "hbm"
+    out["frac"] = max(out["mfma_frac"], out["hbm_frac"])
+    # the reference's loop (one softmax over all candidates per test segment) on the host, bounded sample
+    try:
+        from oracle import bm_oracle as O
+        cand_h, est_h = cand.cpu(), est[:64].cpu()
+        hashes = torch.arange(n_cand)
+        kept = torch.arange(n_cand)
+        prev = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or prev))
+        t0 = time.perf_counter()
+        O.get_wer_loop(est_h[:2], cand_h, hashes, kept)           # calibration (includes the one-off clone)
+        per_query = (time.perf_counter() - t0) / 2
+        done = max(4, min(len(est_h), int(cpu_seconds / max(per_query, 1e-3))))
+        t0 = time.perf_counter()
+        O.get_wer_loop(est_h[:done], cand_h, hashes, kept)
+        dt = time.perf_counter() - t0
+        torch.set_num_threads(prev)
+        out["cpu_loop"] = {"queries_per_s": done / dt, "queries_timed": done, "cores": min(32, os.cpu_count() or prev),
+                           "kind": "port", "sample": f"oracle.get_wer_loop (bm/wer.py:91-116 as written) on {done} "
+                                                     f"queries against the same {n_cand} candidates"}
+    except Exception as exc:
+        out["cpu_loop"] = {"error": repr(exc)}
+    del est, cand
+    torch.cuda.empty_cache()
+    return out
+
+
+def pcie_inclusive_block(workload, B, dev, solver, steps, rank=0, n=4):
+    """The same step with the batches handed over as PINNED HOST tensors (what a DataLoader with pin_memory=True
+    delivers; bm/solver.py:243 `batch.to(device)`): Solver.stage copies batch k + 1 on the copy stream while step k
+    runs.  Never `value`."""
+    c = synthetic.CONFIGS[workload]
+    host = [synthetic.make_batch(B, c["C"], c["T"], c["F"], c["S"], seed=7000 + 1000 * rank + i,
+                                 mixed_eeg=workload == "cfg5").pin() for i in range(n)]
+    mb = sum(t.numel() * t.element_size() for t in (host[0].meg, host[0].features, host[0].features_mask)) / 1e6
+    for i in range(3):
+        solver.train_step(host[i % n], next_batch=host[(i + 1) % n])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = solver.train_step(host[(i + 3) % n], next_batch=host[(i + 4) % n])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "value": B * 1e3 / ms, "unit": "segments/s", "steps": steps,
+            "host_to_device_MB_per_step": mb, "final_loss": float(loss),
+            "how": "pinned host batches, next batch staged on a copy stream during the step (Solver.stage / prefetch)"}
+
+
 def flush_c_stdio():
     """librccl prints a version banner to the C-level stdout when the first communicator comes up; on a pipe that
     text sits in the stdio buffer until exit and would land BEHIND the JSON line.  Flushing right after init (every
@@ -383,6 +502,10 @@ def main():
     ap.add_argument("--no-exact", action="store_true",
                     help="skip the extra timing blocks of the other fp32-class modes (profiling runs)")
     ap.add_argument("--no-clip", action="store_true", help="skip the ClipLoss contraction roofline block")
+    ap.add_argument("--no-side-blocks", action="store_true",
+                    help="skip the sustained / single-stream / pcie-inclusive / retrieval-roofline blocks (A/B and "
+                         "profiling runs)")
+    ap.add_argument("--sustained-steps", type=int, default=200)
     ap.add_argument("--dtype", default=hip_ops.DEFAULT_COMPUTE_DTYPE, choices=sorted(hip_ops.COMPUTE_DTYPES),
                     help="compute mode of the contractions; every fp32-class mode (f16x2, f32x3, f32) is held to the "
                          "same parity tolerances; bf16 is opt-in REDUCED precision, for information only")
@@ -429,11 +552,33 @@ def main():
     elapsed, loss = timed_steps(args.steps)
     final_loss = float(loss)
 
-    # second pass over the same stream with per-launch HIP events (NOT part of `value`)
+    # The step as timed above runs its weight gradients on a second stream next to the data gradients (hip_ops
+    # side_stream_of_backward); a kernel's launch duration is only well defined when it has the chip to itself, so
+    # the per-launch HIP events (NOT part of `value`) are taken in a second pass over the same stream of batches with
+    # that overlap switched off -- and the single-stream step time is reported beside the headline.
+    side_stream_on = hip_ops._WGRAD_STREAM
+    hip_ops.set_wgrad_stream(False)
+    solver.train_step(stream.next()[0])
+    single_stream_elapsed, _ = timed_steps(args.steps)
     timer = hip_ops.KernelTimer()
     hip_ops.set_kernel_timer(timer)
     event_pass_elapsed, _ = timed_steps(args.steps)
     hip_ops.set_kernel_timer(None)
+    hip_ops.set_wgrad_stream(side_stream_on)
+    sustained = pcie = None
+    if not args.no_side_blocks:
+        # `value` comes from the driver's fixed --steps (0.3 s at 20 steps): the same loop over a longer window
+        solver.train_step(stream.next()[0])
+        e_s, _ = timed_steps(args.sustained_steps)
+        sustained = {"steps": args.sustained_steps, "ms_per_step": e_s / args.sustained_steps * 1e3,
+                     "value": world * B * args.sustained_steps / e_s, "unit": "segments/s",
+                     "seconds": e_s}
+        if world == 1:
+            try:
+                pcie = pcie_inclusive_block(args.workload, B, dev, solver, args.steps, rank)
+                pcie["resident_ms_per_step"] = elapsed / args.steps * 1e3
+            except Exception as exc:
+                pcie = {"error": repr(exc)}
 
     # For transparency the same job is also timed in the other fp32-class modes (not part of `value`).
     other_modes = {}
@@ -457,7 +602,11 @@ def main():
     d = ksum[dom]
     achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
     seg_flops = algorithmic_flops_per_segment(c["C"], c["T"], c["F"])
-    traffic, traffic_src = pmc_traffic(dom)
+    traffic, traffic_src, traffic_avg_ms = pmc_traffic(dom)
+    # counters are collected in separate rocprofv3 runs and committed: a summary whose launch duration for this
+    # kernel is off by more than 10 % from what has just been measured describes an older kernel
+    traffic_stale = bool(traffic is not None and traffic_avg_ms and
+                         abs(traffic_avg_ms - d["avg_ms"]) > 0.10 * d["avg_ms"])
     peak_tf = MODE_PEAK_TFLOPS[args.dtype]
     total_kernel_ms = sum(v["avg_ms"] * v["launches"] for v in ksum.values()) / args.steps
     step_bytes = algorithmic_bytes_per_step(c["C"], c["T"], c["F"], B, n_params)
@@ -487,7 +636,9 @@ def main():
                                                 if args.dtype in ("f16x2", "f32x3", "bf16") else None),
                      "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
-                     "traffic_source": traffic_src,
+                     "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                     "traffic_summary_avg_launch_ms": traffic_avg_ms,
+                     "events_taken": "single-stream pass (weight-gradient side stream off): a launch has the chip to itself",
                      "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,
                      "median_launch_ms": d["median_ms"],
                      "event_outliers_dropped": {k: v["outliers"] for k, v in ksum.items() if v["outliers"]},
@@ -499,6 +650,12 @@ def main():
                      "hbm_roofline_frac_step": step_bytes / (PEAK_HBM_GBS * 1e9) / (elapsed / args.steps),
                      "algorithmic_bytes_per_step": step_bytes},
     }
+    out["overlap"] = {"weight_gradients_on_side_stream": bool(side_stream_on),
+                      "single_stream_ms_per_step": single_stream_elapsed / args.steps * 1e3,
+                      "ms_per_step": elapsed / args.steps * 1e3,
+                      "side_stream_launches_total": hip_ops.side_stream_launches}
+    out["sustained"] = sustained
+    out["pcie_inclusive"] = pcie
     out["other_fp32_modes"] = other_modes or None
     out["exact_f32_mfma"] = other_modes.get("f32")
     out["roofline_clip"] = None
@@ -507,6 +664,12 @@ def main():
             out["roofline_clip"] = clip_roofline(dev, args.dtype)
         except Exception as exc:
             out["roofline_clip"] = {"error": repr(exc)}
+    out["roofline_retrieval"] = None
+    if world == 1 and not args.no_side_blocks and args.workload == "cfg2":
+        try:
+            out["roofline_retrieval"] = retrieval_roofline(dev, args.dtype)
+        except Exception as exc:
+            out["roofline_retrieval"] = {"error": repr(exc)}
     out["retrieval"] = None
     out["retrieval_parity"] = None
     if world == 1 and args.accuracy_steps > 0:

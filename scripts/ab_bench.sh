@@ -6,7 +6,7 @@ cd $R; mkdir -p gpurun_out
 TAG=$1; shift
 i=0
 run() {
-  env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip \
+  env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip --no-side-blocks \
       > gpurun_out/${TAG}_ab_$2.json 2> gpurun_out/${TAG}_ab_$2.err
   python - "$1" gpurun_out/${TAG}_ab_$2.json <<'PY'
 import json, sys

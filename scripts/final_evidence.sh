@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 TAG=${1:-final}
 bash scripts/gpu_check.sh $TAG 1500 prof 2>&1 | tail -30
-SIDE="--no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip"
+SIDE="--no-cpu-baseline --accuracy-steps 0 --no-exact --no-clip --no-side-blocks"
 timeout 300 python bench.py --workload cfg3 $SIDE > gpurun_out/${TAG}_bench_cfg3.json 2>/dev/null; echo "cfg3 rc=$?"
 timeout 300 python bench.py --workload cfg5 $SIDE > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null; echo "cfg5 rc=$?"
 timeout 300 python bench.py --steps 200 --warmup 5 $SIDE > gpurun_out/${TAG}_bench_sustained_200steps.json 2>/dev/null; echo "sustained rc=$?"

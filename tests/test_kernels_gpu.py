@@ -275,6 +275,46 @@ def test_clip_kernels(H, B, Bc, Fd, T):
     assert rel_l2(dest.view(B, Fd, T), est.grad) < GRAD_TOL
 
 
+def test_clip_loss_at_the_whole_node_shape(H):
+    """cfg4 (BASELINE configs[3]): 256 estimates of one rank against the 2 048 candidates of 8 ranks (mel features,
+    K = 120 * 360 -- the shape the driver's 8-GPU run puts through ClipLoss), targets = the rank's own block at
+    target_offset = 7 * 256 (rank 7), a few padding candidates masked (per-rank rejection).  Loss, probabilities of the
+    target block and dEst against the fp32 CPU oracle (own block rolled to the front, masked candidates removed)."""
+    from brainmagick_amd.losses import ClipLoss
+    B, Bc, Fd, T, off = 256, 2048, 120, 360, 7 * 256
+    g = _gen(77)
+    est = (torch.randn(B, Fd, T, generator=g) * 0.5).requires_grad_(True)
+    cand = torch.randn(Bc, Fd, T, generator=g)
+    est.data += 0.4 * cand[off:off + B]                       # planted: a non-trivial softmax
+    valid = torch.ones(Bc)
+    masked = [3, 300, 301, 1500, 2047]
+    valid[masked] = 0
+    kept = torch.tensor([i for i in range(Bc) if i not in masked and not off <= i < off + B])
+    cand_ref = torch.cat([cand[off:off + B], cand[kept]])     # bm/losses.py:105-111: the first B candidates are the targets
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(32, prev))
+    try:
+        loss_ref = O.clip_loss(est, cand_ref)
+        loss_ref.backward()
+    finally:
+        torch.set_num_threads(prev)
+    eg = est.detach().cuda().requires_grad_(True)
+    cg = cand.cuda()
+    loss = ClipLoss().cuda()(eg, cg, torch.ones(B, 1, T, dtype=torch.bool, device="cuda"), target_offset=off,
+                              candidate_valid=valid.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4, (float(loss), float(loss_ref))
+    assert rel_l2(eg.grad, est.grad) < GRAD_TOL, rel_l2(eg.grad, est.grad)
+    # a masked candidate has probability exactly 0 and takes no gradient share
+    from brainmagick_amd import functional as BF
+    inv = H.clip_inv_norms(cg)
+    part = BF._clip_raw_scores(eg.detach(), cg, B, Bc, Fd * T)
+    _, probs, dscaled, _ = H.clip_ce(part, inv, want_probs=True, want_grad=True, want_loss=True, target_offset=off,
+                                     col_valid=valid.cuda())
+    assert float(probs[:, masked].abs().max()) == 0.0 and float(dscaled[:, masked].abs().max()) == 0.0
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-5
+
+
 def test_adam_kernel(H):
     g = _gen(2)
     n = 10007

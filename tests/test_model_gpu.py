@@ -514,22 +514,25 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible(tmp_path):
         assert p.returncode == 0 and f"TWO_RANK_OK {r}" in out, out
 
 
-@pytest.mark.parametrize("negatives", ["local", "node"])
-def test_two_replicas_match_the_data_parallel_oracle(negatives):
-    """SURVEY.md §8(c) data-parallel oracle against the HIP path at world size 2 on ONE GPU: two `Solver` replicas
-    run the unmodified `train_step` in two threads under an in-process loopback communicator (tests/loopback.py:
+@pytest.mark.parametrize("negatives,world", [("local", 2), ("node", 2), ("node", 4), ("node", 8)])
+def test_replicas_match_the_data_parallel_oracle(negatives, world):
+    """SURVEY.md §8(c) data-parallel oracle against the HIP path at world size 2, 4 and 8 on ONE GPU: `world` `Solver`
+    replicas run the unmodified `train_step` in threads under an in-process loopback communicator (tests/loopback.py:
     the same interface as the RCCL communicator -- candidate all-gather + target_offset, in-place reduce-scatter
     of the flat gradient bucket, sharded Adam, in-place all-gather of the parameters, buffer all-reduce).
     Expectation = the oracle run once per rank on that rank's batch ("node": against the candidates of BOTH
     ranks, own block as targets), gradients averaged over the ranks (flashy.distrib.sync_model, bm/solver.py:386),
     one Adam step on the mean, BatchNorm running statistics averaged, per-rank batch statistics.  Then a
     checkpoint (`Solver.state_dict()`, which gathers the sharded Adam moments) is loaded into fresh replicas that
-    must continue bit-identically."""
+    must continue bit-identically.  At world 4 and 8 the replicas also hand over the NEXT batch (host tensors: staged
+    on the copy stream; its candidate all-gather is prefetched next to the backward pass) -- rank 7's targets are the
+    block at target_offset = 7 B of 8 B candidates."""
     from loopback import run_replicas
     from brainmagick_amd import distrib
     from brainmagick_amd.models import SimpleConv
     from brainmagick_amd.solver import Solver
-    world, B, steps = 2, 8, 2
+    B, steps = 8, 2
+    prefetch = world > 2
     cfg = dict(O.CLIP_CONV_CFG)
     cfg.update(merger_pos_dim=128, merger_channels=96, initial_linear=96, depth=4, merger_dropout=0.0)
     C, T, Fd, S, hidden = 30, 160, 12, 4, 96
@@ -552,7 +555,8 @@ def test_two_replicas_match_the_data_parallel_oracle(negatives):
         lo, hi = distrib.shard_bounds(solver.optimizer.padded, world, r)
         out = dict(losses=[], names=names, offsets=list(solver.optimizer.offsets), shard=(lo, hi))
         for k in range(steps):
-            out["losses"].append(float(solver.train_step(batches[r][k])))
+            out["losses"].append(float(solver.train_step(batches[r][k],
+                                                         next_batch=batches[r][k + 1] if prefetch else None)))
             if k == 0:
                 out["grad_shard"] = solver.optimizer.flat_grad[lo:hi].clone().cpu()      # sum over the ranks
         out["flat_param"] = solver.optimizer.flat_param.clone().cpu()
@@ -571,8 +575,9 @@ def test_two_replicas_match_the_data_parallel_oracle(negatives):
         return out
 
     res = run_replicas(world, body)
-    assert torch.equal(res[0]["flat_param"], res[1]["flat_param"]), "replicas diverged"
-    assert torch.equal(res[0]["exp_avg"], res[1]["exp_avg"]), "gathered moments differ between ranks"
+    for r in range(1, world):
+        assert torch.equal(res[0]["flat_param"], res[r]["flat_param"]), "replicas diverged"
+        assert torch.equal(res[0]["exp_avg"], res[r]["exp_avg"]), "gathered moments differ between ranks"
 
     # the data-parallel oracle
     oracles = [O.OracleModel(copy.deepcopy(sd0), cfg, hidden, Fd) for _ in range(world)]
@@ -1097,3 +1102,162 @@ def test_gradients_collected_by_copy_equal_accumulated_ones():
     opt.zero_grad(set_to_none=True)
     opt.collect_grads()
     assert float(opt.flat_grad[:opt.numel].abs().max()) == 0.0
+
+
+def test_replicas_with_per_rank_rejection_and_whole_node_negatives():
+    """negatives="node" next to a ScaleReject that REJECTS (clip=False, bm/norm.py:335-343): the ranks end up with
+    different numbers of segments; every rank still gathers equal blocks of the nominal batch size, the rejected rows
+    are padding and ClipLoss masks them.  Loopback world 3; oracle = per-rank loss over the rank's kept segments
+    against the kept candidates of all ranks (own ones first), gradients averaged over the ranks."""
+    from loopback import run_replicas
+    from brainmagick_amd import distrib
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
+    from brainmagick_amd.solver import Solver
+    world, B = 3, 8
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=48, initial_linear=48, depth=2, merger_dropout=0.0)
+    C, T, Fd, S, hidden = 24, 136, 10, 3, 48
+
+    def build():
+        torch.manual_seed(3)
+        return SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
+
+    sd0 = copy.deepcopy(build().state_dict())
+    recordings = synthetic.make_layouts(2, [C], torch.Generator().manual_seed(5))
+    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=90 + r, recordings=recordings) for r in range(world)]
+    rejected = {0: [], 1: [2, 5], 2: [0, 1, 7]}                 # rank -> segments pushed over the limit
+    for r, rows in rejected.items():
+        for i in rows:
+            batches[r].meg[i, 3, 10] = 19.0                      # > limit 16 (the synthetic clamp is +-20)
+    keep = [[i for i in range(B) if i not in rejected[r]] for r in range(world)]
+
+    def body(r):
+        model = build()
+        scaler = DeviceBatchScaler(torch.zeros(2, C), torch.ones(2, C))
+        solver = Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=False))
+        loss = float(solver.train_step(batches[r]))
+        opt = solver.optimizer
+        lo, hi = distrib.shard_bounds(opt.padded, world, r)
+        return dict(loss=loss, shard=(lo, hi), grad_shard=opt.flat_grad[lo:hi].clone().cpu(),
+                    names=[k for k, _ in model.named_parameters()], offsets=list(opt.offsets))
+
+    res = run_replicas(world, body)
+    per_rank = []
+    for r in range(world):
+        sb = batches[r]
+        own = sb.features[keep[r]]
+        others = [batches[q].features[keep[q]] for q in range(world) if q != r]
+        oracle = O.OracleModel(copy.deepcopy(sd0), cfg, hidden, Fd)
+        loss, _, grads = oracle.loss_and_grads(sb.meg[keep[r]], sb.positions()[keep[r]], sb.subject_index[keep[r]],
+                                               torch.cat([own] + others), True)
+        assert abs(res[r]["loss"] - float(loss)) < LOSS_TOL, (r, res[r]["loss"], float(loss))
+        per_rank.append(grads)
+    mean = {n: sum(g[n] for g in per_rank) / world for n in per_rank[0]}
+    full = torch.zeros(max(res[0]["offsets"]) + 10 ** 6, dtype=torch.float64)
+    for n, off in zip(res[0]["names"], res[0]["offsets"]):
+        full[off:off + mean[n].numel()] = mean[n].reshape(-1).double()
+    for r in range(world):
+        lo, hi = res[r]["shard"]
+        assert rel_l2(res[r]["grad_shard"] / world, full[lo:hi]) < GRAD_TOL, r
+
+
+def test_host_batches_on_the_copy_stream_and_the_side_stream_change_no_bit():
+    """(1) bm/solver.py:243: batches handed over as PINNED host tensors, the next one staged on the copy stream while
+    the step runs (Solver.stage / train_step(next_batch=...)), against the same batches resident on the device; (2) the
+    weight gradients on the second stream (hip_ops.side_stream_of_backward) against one stream.  Three steps each:
+    losses and parameters must be bit-identical -- streams change when kernels run, never what they compute."""
+    from brainmagick_amd import hip_ops as H
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.models import SimpleConv
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=96, initial_linear=96, depth=4, merger_dropout=0.0)
+    C, T, Fd, S, hidden, B = 30, 160, 12, 4, 96, 16
+    recordings = synthetic.make_layouts(2, [C], torch.Generator().manual_seed(9))
+    host = [synthetic.make_batch(B, C, T, Fd, S, seed=300 + k, recordings=recordings) for k in range(4)]
+
+    def run(mode):
+        torch.manual_seed(0)
+        model = SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
+        solver = Solver(model)
+        H.set_wgrad_stream(mode != "one_stream")
+        before = H.side_stream_launches
+        try:
+            if mode == "pinned":
+                batches = [b.pin() for b in host]
+                assert batches[0].meg.is_pinned()
+                losses = [float(solver.train_step(batches[k], next_batch=batches[k + 1])) for k in range(3)]
+            else:
+                batches = [b.to("cuda") for b in host]
+                losses = [float(solver.train_step(batches[k])) for k in range(3)]
+        finally:
+            H.set_wgrad_stream(True)
+        return losses, solver.optimizer.flat_param.clone(), H.side_stream_launches - before
+
+    base_l, base_p, n_side = run("resident")
+    assert n_side > 0, "the weight gradients did not go to the side stream"
+    for mode in ("pinned", "one_stream"):
+        l, p_, n = run(mode)
+        assert l == base_l, (mode, l, base_l)
+        assert torch.equal(p_, base_p), mode
+        assert (n == 0) == (mode == "one_stream")
+
+
+def test_flat_bucket_views_are_handed_out_only_inside_writing_grads():
+    """a gradient that aliases the optimizer's flat bucket may only come out of the training step's own
+    backward pass (`with optimizer.writing_grads()`); torch.autograd.grad for analysis gets fresh tensors."""
+    from brainmagick_amd.solver import Solver
+    model, _ = _small_model(merger_dropout=0.0)
+    solver = Solver(model)
+    opt = solver.optimizer
+    sb = synthetic.make_batch(4, 20, 40, 10, 3, seed=8)
+    lo, hi = opt.flat_grad.data_ptr(), opt.flat_grad.data_ptr() + 4 * opt.padded
+
+    def loss_of():
+        estimate, output, mask, _ = solver._process_batch(sb, training=True)
+        return solver.loss(estimate, output, mask)
+
+    opt.zero_grad(set_to_none=True)
+    grads = torch.autograd.grad(loss_of(), opt.params, allow_unused=True)
+    assert all(g is None or not (lo <= g.data_ptr() < hi) for g in grads)
+    opt.zero_grad(set_to_none=True)
+    with opt.writing_grads():
+        loss_of().backward()
+    inside = sum(1 for p in opt.params if p.grad is not None and lo <= p.grad.data_ptr() < hi)
+    assert inside > 0, "no weight gradient was written straight into the bucket"
+    opt.collect_grads()
+    direct = opt.flat_grad.clone()
+    opt.zero_grad(set_to_none=True)
+    loss_of().backward()                              # outside the context: fresh tensors, collected by copy
+    assert all(p.grad is None or not (lo <= p.grad.data_ptr() < hi) for p in opt.params)
+    opt.collect_grads()
+    assert torch.equal(opt.flat_grad, direct)
+
+
+def test_negative_pool_completes_the_candidates_like_the_reference():
+    """bm/solver.py:358-371 (`optim.negatives`): a batch with fewer candidates than `n_negatives` is completed with
+    a random draw (torch.randperm) from the pool of earlier candidate sets, and the pool takes the completed set in
+    front, cut to `negative_pool_size`.  Restated here on the CPU with the same generator seed; the loss of each
+    step against the oracle's ClipLoss over the completed candidates."""
+    from brainmagick_amd.solver import Solver
+    model, _ = _small_model(merger_dropout=0.0)
+    n_neg, pool_size, B = 10, 14, 6
+    solver = Solver(model, n_negatives=n_neg, negative_pool_size=pool_size)
+    solver.negative_generator = torch.Generator().manual_seed(123)
+    ref_gen = torch.Generator().manual_seed(123)
+    buf = torch.zeros(0, 10, 40)
+    for k in range(4):
+        sb = synthetic.make_batch(B, 20, 40, 10, 3, seed=600 + k)
+        with torch.no_grad():
+            solver.model.train(False)
+            estimate, output, mask, _ = solver._process_batch(sb, training=False)
+            completed = solver._complete_with_pool(output, training=True)
+        out_ref = sb.features
+        n_kept = n_neg - len(out_ref)
+        kept = torch.randperm(len(buf), generator=ref_gen)[:n_kept]
+        out_ref = torch.cat([out_ref, buf[kept]], dim=0)
+        buf = torch.cat([out_ref, buf])[:pool_size]
+        assert torch.equal(completed.cpu(), out_ref), k
+        assert torch.equal(solver.negative_pool["train"].cpu(), buf), k
+        loss = solver.loss(estimate, completed, mask)
+        assert abs(float(loss) - float(O.clip_loss(estimate.cpu(), out_ref))) < LOSS_TOL
