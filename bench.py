@@ -401,6 +401,8 @@ def pcie_inclusive_block(workload, B, dev, solver, steps, rank=0, n=4):
         loss = solver.train_step(host[(i + 3) % n], next_batch=host[(i + 4) % n])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    if not bool(torch.isfinite(loss)):
+        raise RuntimeError("non-finite loss in the pcie-inclusive block")
     return {"ms_per_step": ms, "value": B * 1e3 / ms, "unit": "segments/s", "steps": steps,
             "host_to_device_MB_per_step": mb, "final_loss": float(loss),
             "how": "pinned host batches, next batch staged on a copy stream during the step (Solver.stage / prefetch)"}
@@ -551,6 +553,9 @@ def main():
         solver.train_step(cur, next_batch=nxt if prefetch else None)
     elapsed, loss = timed_steps(args.steps)
     final_loss = float(loss)
+    if final_loss != final_loss or abs(final_loss) == float("inf"):
+        # a throughput number of a diverged run is worthless (and flattering: the matrix pipe clocks higher on NaNs)
+        raise SystemExit(f"bench: the training loss is not finite after the timed region ({final_loss})")
 
     # The step as timed above runs its weight gradients on a second stream next to the data gradients (hip_ops
     # side_stream_of_backward); a kernel's launch duration is only well defined when it has the chip to itself, so

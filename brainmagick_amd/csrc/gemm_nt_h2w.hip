@@ -56,6 +56,10 @@ struct GemmNTArgsH {
     float* part;
     int S, M, Cn, T, dil, nsplit;
     int tiles_m, tiles_c;
+    // grouped contraction (per-(layout, subject) weight gradient of the composed front end): group g contracts the
+    // segments order[seg[g] .. seg[g + 1]) (order nullable = identity); part[g][split][M][N].  Null seg: one group
+    // of all S segments.  Not with the flat walk.
+    const int* order; const int* seg;
 };
 
 // same scale rule as conv_nn_h2w.hip: power of two s with amax * s in [2^14, 2^15), exact inverse
@@ -208,12 +212,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 
     int id = bm_xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id % a.tiles_m; id /= a.tiles_m;
-    const int tc = id % a.tiles_c;
-    const int split = id / a.tiles_c;
+    const int tc = id % a.tiles_c; id /= a.tiles_c;
+    const int split = id % a.nsplit;
+    const int grp = id / a.nsplit;                    // 0 unless grouped
     const int m0 = tm * BM, c0 = tc * BC;
+    const int s_first = a.seg ? a.seg[grp] : 0;       // the group's range in `order` (wave-uniform scalars)
+    const int s_count = a.seg ? a.seg[grp + 1] - s_first : a.S;
+    // segment number of the group's k-th segment
+#define HG_SEG(K_) (a.order ? a.order[s_first + (K_)] : s_first + (K_))
 
     const int cps = (a.T + HG_K - 1) / HG_K;
-    const long nchunks = FL ? ((long)a.S * a.T + HG_K - 1) / HG_K : (long)a.S * cps;
+    const long nchunks = FL ? ((long)a.S * a.T + HG_K - 1) / HG_K : (long)s_count * cps;
     const long q_begin = nchunks * split / a.nsplit;
     const long q_end = nchunks * (split + 1) / a.nsplit;
     const int nst = (int)(q_end - q_begin);
@@ -285,8 +294,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     int ld_s = FL ? 0 : (int)(q_begin / cps);
     int ld_c = FL ? 0 : (int)(q_begin - (long)ld_s * cps);
     // segment descriptors, rebuilt only when the cursor enters a new segment (FL: the whole tensors, once)
-    __amdgpu_buffer_rsrc_t qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);
-    __amdgpu_buffer_rsrc_t qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);
+    const int seg0 = (FL || nst <= 0) ? 0 : HG_SEG(ld_s);
+    __amdgpu_buffer_rsrc_t qa = hg_rsrc(a.a + (long)seg0 * a.a_sstride, a_bytes);
+    __amdgpu_buffer_rsrc_t qx = hg_rsrc(a.x + (long)seg0 * a.x_sstride, x_bytes);
     int vn, vx[NXS];                                   // byte offset of the chunk to fetch (X: per tap)
     unsigned vna = 0;                                  // RS: the same for A, out of range when this lane's piece lies past T
     // FL: this lane's piece of the chunk at the cursor -- segment ls, local time lt (a multiple of 4), byte offsets
@@ -326,8 +336,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
             }                                                                                     \
         } else if (++ld_c == cps) {                                                               \
             ld_c = 0; ++ld_s;                                                                     \
-            qa = hg_rsrc(a.a + (long)ld_s * a.a_sstride, a_bytes);                                \
-            qx = hg_rsrc(a.x + (long)ld_s * a.x_sstride, x_bytes);                                \
+            const int sg_ = HG_SEG(ld_s);                                                         \
+            qa = hg_rsrc(a.a + (long)sg_ * a.a_sstride, a_bytes);                                 \
+            qx = hg_rsrc(a.x + (long)sg_ * a.x_sstride, x_bytes);                                 \
         }                                                                                         \
     }
     // fetch of piece I_ of the chunk at the cursor: the whole offset travels in the per-lane address, which the
@@ -485,6 +496,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) hg_trace_buf[(blockIdx.x * 4 + wave) * 8 + i_] = (long long)tacc[i_];
 #endif
     }
+#undef HG_SEG
 #undef HG_SET_SCALES
 #undef HG_MARK
 #undef HG_CHUNK_OFFSETS
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     // partial tile out (inverse scales are exact powers of two): KS = 3: part[split][m][c * 3 + j];
     // KS = 1: part[split][m][c0 + 64 j + ...]
     const long N = (long)a.Cn * KS;
-    float* dst = a.part + (long)split * a.M * N;
+    float* dst = a.part + ((long)grp * a.nsplit + split) * a.M * N;
     if constexpr (RS) {
         // the rows' inverse scales, once per workgroup into the (now free) LDS: 80 rows per lane below
         __syncthreads();
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
     if constexpr (TS) {
         // element r of a lane: row (r & 3) + 8 (r >> 2) + 4 h of the block -- rows 4 q' .. 4 q' + 3 are r = 4 q .. 4 q + 3
         const float f = sa_inv * sx_inv;
-        float* dstT = a.part + (long)split * a.Cn * a.M;
+        float* dstT = a.part + ((long)grp * a.nsplit + split) * a.Cn * a.M;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int c = c0 + 64 * j + wc * 32 + nl;
@@ -587,14 +599,18 @@ static int hg_flat_axis() {
 
 // tile family of a shape: 0 = not covered, 1 = 320 x 192 (<KS,5,3>), 2 = 256 x 128 (<1,4,2>)
 static int hg_family(int S, int G, int M, int Cn, int T, int KS, int dil, bool ordered) {
-    static int wide = -1;
+    static int wide = -1, grouped = -1;
     if (wide < 0) {
         const char* e = getenv("BM_H2_WIDE");          // BM_H2_WIDE=0: A/B runs against the 3 x bf16 kernels
         wide = !(e && e[0] == '0');
+        const char* e2 = getenv("BM_H2_GROUPED");      // BM_H2_GROUPED=0: grouped contractions on the narrow kernels (A/B)
+        grouped = !(e2 && e2[0] == '0');
     }
-    if (!wide || G != 1 || ordered || (KS != 3 && KS != 1)) return 0;
+    if (!wide || (KS != 3 && KS != 1)) return 0;
+    // grouped (order / seg) contractions: the 1x1 tile families, per-segment walk, per-tensor scales
+    if ((G != 1 || ordered) && (!grouped || KS != 1)) return 0;
     if (dil < 1 || dil > 32 || T < 2 * HG_K) return 0;
-    if ((long)S * ((T + HG_K - 1) / HG_K) < 32) return 0;
+    if ((long)S * ((T + HG_K - 1) / HG_K) < 32L * G) return 0;
     // padded rows / columns are wasted MFMA work: at most 25 % (3 taps) / 50 % (1x1 layers, small in absolute terms)
     const long work = (long)M * Cn;
     const long pad53 = (long)cdiv(M, 320) * 320 * cdiv(Cn, KS == 3 ? 64 : 192) * (KS == 3 ? 64 : 192);
@@ -609,10 +625,16 @@ extern "C" int bm_gemm_nt_h2_covers(int M, int Cn, int KS, int S, int T, int G, 
 }
 
 // one workgroup per CU per round (256 CUs), >= 8 stages (of 32 samples) per workgroup
+extern "C" int bm_gemm_nt_h2_suggest_splits_grouped(int M, int Cn, int KS, int S, int T, int G);
 extern "C" int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T) {
-    const int fam = hg_family(S, 1, M, Cn, T, KS, 1, false);
-    const int tiles = fam == 2 ? cdiv(M, 256) * cdiv(Cn, 128) : cdiv(M, 320) * cdiv(Cn, KS == 3 ? 64 : 192);
-    const long chunks = (long)S * ((T + HG_K - 1) / HG_K);
+    return bm_gemm_nt_h2_suggest_splits_grouped(M, Cn, KS, S, T, 1);
+}
+// G groups of ~S / G segments each: splits per group so that ~256 workgroups exist, >= 8 stages each
+extern "C" int bm_gemm_nt_h2_suggest_splits_grouped(int M, int Cn, int KS, int S, int T, int G) {
+    if (G < 1) G = 1;
+    const int fam = hg_family(S, G, M, Cn, T, KS, 1, G > 1);
+    const int tiles = (fam == 2 ? cdiv(M, 256) * cdiv(Cn, 128) : cdiv(M, 320) * cdiv(Cn, KS == 3 ? 64 : 192)) * G;
+    const long chunks = (long)(S / G > 0 ? S / G : 1) * ((T + HG_K - 1) / HG_K);
     long want = 256 / tiles;
     if (want > chunks / 8) want = chunks / 8;
     if (want < 1) want = 1;
@@ -620,7 +642,7 @@ extern "C" int bm_gemm_nt_h2_suggest_splits(int M, int Cn, int KS, int S, int T)
 }
 
 template <int KS, int MW, int NS, bool RS = false, bool TS = false, bool FL = false>
-static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
+static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream, int ngroups = 1) {
     constexpr int PLANE = 4 * (64 * MW + 2) + NS * 4 * HG_XQ;
     const size_t lds = (size_t)2 * 2 * PLANE * 16;
     static bool attr_set = false;
@@ -632,7 +654,7 @@ static int launch_gemm_nt_h2w(GemmNTArgsH g, hipStream_t stream) {
     }
     g.tiles_m = cdiv(g.M, 64 * MW);
     g.tiles_c = cdiv(g.Cn, KS == 3 ? 64 : 64 * NS);
-    const long nblocks = (long)g.tiles_m * g.tiles_c * g.nsplit;
+    const long nblocks = (long)g.tiles_m * g.tiles_c * g.nsplit * ngroups;
     hipLaunchKernelGGL((gemm_nt_h2w_kernel<KS, MW, NS, RS, TS, FL>), dim3((unsigned)nblocks), dim3(256), lds, stream, g);
     return bm_check_launch("gemm_nt_h2w");
 }
@@ -643,22 +665,30 @@ extern "C" int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, con
 
 static int gemm_nt_h2_impl(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* a_row_amax,
                            const float* x, long x_sstride, long x_rstride, const float* x_amax, float* part, int S,
-                           int M, int Cn, int T, int KS, int dil, int nsplit, void* stream) {
+                           int M, int Cn, int T, int KS, int dil, int nsplit, void* stream,
+                           const int* order = nullptr, const int* seg = nullptr, int G = 1) {
     BM_REQUIRE(a && x && part && a_amax && x_amax, "gemm_nt_h2: null pointer");
     BM_REQUIRE(M > 0 && Cn > 0 && T > 0 && nsplit > 0 && S >= 0, "gemm_nt_h2: bad dims");
-    const int fam = hg_family(S, 1, M, Cn, T, KS, dil, false);
+    BM_REQUIRE(G >= 1 && (G == 1 || seg), "gemm_nt_h2: a grouped call needs seg[]");
+    const bool grouped = seg != nullptr || order != nullptr;
+    const int fam = hg_family(S, G, M, Cn, T, KS, dil, grouped);
     BM_REQUIRE(fam != 0, "gemm_nt_h2: shape not covered (M=%d Cn=%d T=%d KS=%d dil=%d)", M, Cn, T, KS, dil);
     // 32-bit byte offsets inside a segment: an operand whose segment spans 2 GB or more (2 048 wav2vec2-sized
     // candidates on 8 GPUs) takes the 3 x bf16 entry point, which hands it to the 64-bit-addressed fp32 kernel
     if (((long)(M - 1) * a_rstride + T) * 4 >= 0x7f000000L || ((long)(Cn - 1) * x_rstride + T) * 4 >= 0x7f000000L)
-        return bm_gemm_nt_x3(a, a_sstride, a_rstride, x, x_sstride, x_rstride, nullptr, nullptr, part, S, 1, M, Cn, T,
+        return bm_gemm_nt_x3(a, a_sstride, a_rstride, x, x_sstride, x_rstride, order, seg, part, S, G, M, Cn, T,
                              KS, dil, nsplit, stream);
     GemmNTArgsH g;
     g.a = a; g.a_sstride = a_sstride; g.a_rstride = a_rstride; g.a_amax = a_amax;
     g.x = x; g.x_sstride = x_sstride; g.x_rstride = x_rstride; g.x_amax = x_amax;
     g.a_row_amax = a_row_amax;
     g.part = part; g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit;
+    g.order = order; g.seg = seg;
     hipStream_t s = (hipStream_t)stream;
+    if (grouped) {          // per-segment walk, per-tensor scales: the two 1x1 tile families
+        if (fam == 2) return launch_gemm_nt_h2w<1, 4, 2>(g, s, G);
+        return launch_gemm_nt_h2w<1, 5, 3>(g, s, G);
+    }
     // per-row scales of A: the 320-row tiles, rows contiguous in time (pieces of 4 samples never straddle a row)
     const bool rs = a_row_amax && fam == 1 && T % 4 == 0 && a_rstride % 4 == 0 && a_sstride % 4 == 0;
     // flat time axis (no per-segment padding of T to a multiple of 32): row-scaled 3-tap weight gradients whose
@@ -692,6 +722,16 @@ extern "C" int bm_gemm_nt_h2_rows(const float* a, long a_sstride, long a_rstride
                                   int nsplit, void* stream) {
     return gemm_nt_h2_impl(a, a_sstride, a_rstride, a_amax, a_row_amax, x, x_sstride, x_rstride, x_amax, part, S, M, Cn,
                            T, KS, dil, nsplit, stream);
+}
+
+// Grouped form: part[g][split][m][c] = sum over the segments order[seg[g] .. seg[g + 1]) (order nullable = identity)
+// and the split's share of their samples.  KS = 1 only (the per-(layout, subject) / per-subject weight gradients).
+extern "C" int bm_gemm_nt_h2_grouped(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* x,
+                                     long x_sstride, long x_rstride, const float* x_amax, const int* order,
+                                     const int* seg, float* part, int S, int G, int M, int Cn, int T, int nsplit,
+                                     void* stream) {
+    return gemm_nt_h2_impl(a, a_sstride, a_rstride, a_amax, nullptr, x, x_sstride, x_rstride, x_amax, part, S, M, Cn, T,
+                           1, 1, nsplit, stream, order, seg, G);
 }
 
 // ---- ClipLoss score contraction (bm/losses.py:94, the einsum "bct,oct->bo" before the candidate norms) ----
@@ -738,6 +778,7 @@ extern "C" int bm_clip_scores_h2(const float* est, const float* est_amax, const 
     g.a = cand; g.a_sstride = 0; g.a_rstride = K; g.a_amax = cand_amax; g.a_row_amax = nullptr;
     g.x = est; g.x_sstride = 0; g.x_rstride = K; g.x_amax = est_amax;
     g.part = part; g.S = 1; g.M = Bc; g.Cn = B; g.T = (int)K; g.dil = 1; g.nsplit = nsplit;
+    g.order = nullptr; g.seg = nullptr;
     if (clip_scores_wide(B, Bc, K)) return launch_gemm_nt_h2w<1, 4, 4, false, true>(g, (hipStream_t)stream);
     return launch_gemm_nt_h2w<1, 4, 2, false, true>(g, (hipStream_t)stream);
 }

@@ -501,14 +501,23 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
     if out is None:
         out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
     mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
+    grouped = order is not None or seg is not None
     if mode == "f16x2":
         # rows T apart; the segment stride only matters when there is more than one segment
         contiguous = a_strides[1] == T and x_strides[1] == T and \
             (S == 1 or (a_strides[0] == M * T and x_strides[0] == Cn * T))
-        if not (contiguous and lib().bm_gemm_nt_h2_covers(M, Cn, KS, S, T, G, dil, int(order is not None))):
+        covered = contiguous and lib().bm_gemm_nt_h2_covers(M, Cn, KS, S, T, G, dil, int(grouped))
+        if contiguous and not covered and KS == 1 and lib().bm_gemm_nt_h2_covers(Cn, M, KS, S, T, G, dil, int(grouped)):
+            # sum_t a[m][t] x[c][t] is symmetric in its operands: with the roles swapped the (M, Cn) rectangle may fit
+            # the wide tiles (208 x 270 per (layout, subject) pair: 256 x 128 tiles) where (270, 208) does not --
+            # the result lands through the swapped output strides
+            a, x, M, Cn, a_strides, x_strides = x, a, Cn, M, x_strides, a_strides
+            out_strides = (out_strides[0], out_strides[2], out_strides[1], out_strides[3])
+            covered = True
+        if not covered:
             mode = "f32x3"      # shapes without a wide f16x2 kernel: the (equally fp32-accurate) 3 x bf16 kernels
         elif nsplit is None:
-            nsplit = lib().bm_gemm_nt_h2_suggest_splits(M, Cn, KS, S, T)
+            nsplit = lib().bm_gemm_nt_h2_suggest_splits_grouped(M, Cn, KS, S, T, G)
     if nsplit is None:
         if mode == "f32x3" and order is None:
             nsplit = lib().bm_gemm_nt_x3_suggest_splits(M, Cn, KS, S, T, G, dil)
@@ -533,6 +542,12 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
             a_rows = None
 
         def launch():
+            if grouped:
+                check(lib().bm_gemm_nt_h2_grouped(_p(a), a_strides[0], a_strides[1], _p(a_amax), _p(x), x_strides[0],
+                                                  x_strides[1], _p(x_amax), _p(_opt(order, "order", torch.int32)),
+                                                  _p(_opt(seg, "seg", torch.int32)), _p(part), S, G, M, Cn, T, nsplit,
+                                                  _stream()), "bm_gemm_nt_h2_grouped")
+                return
             check(lib().bm_gemm_nt_h2_rows(_p(a), a_strides[0], a_strides[1], _p(a_amax), _p(a_rows), _p(x),
                                            x_strides[0], x_strides[1], _p(x_amax), _p(part), S, M, Cn, T, KS, dil,
                                            nsplit, _stream()), "bm_gemm_nt_h2")
@@ -543,6 +558,10 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
             check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
                      _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)), _p(part), S,
                      G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
+    if _on_side_stream is not None:
+        _protect_on_side_stream(a, x, out, order, seg)
+        if mode == "f16x2":
+            _protect_on_side_stream(a_amax, x_amax, a_rows)
     if _timer is not None:
         suffix = {"f32": "", "bf16": "_bf16", "f32x3": "_x3", "f16x2": "_h2w"}[mode]
         _timer.launch(f"gemm_nt{suffix}_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS, launch)
@@ -591,6 +610,21 @@ def join_side_streams():
         _join_side_stream(key)
 
 
+_on_side_stream: tp.Optional[torch.cuda.Stream] = None     # set while a side_stream_of_backward block runs
+
+
+def _protect_on_side_stream(*tensors):
+    """Every tensor a kernel launched on the side stream reads or writes -- the operands, but also the small ones
+    that travel with them (per-row maxima, amax slots, index tables) -- must not be recycled by the caching allocator
+    of the stream that owns it while the side stream still uses it: a 1 280-byte row-maxima buffer freed with its
+    gradient tensor is handed to the next layer's launch within microseconds."""
+    side = _on_side_stream
+    if side is not None:
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(side)
+
+
 class side_stream_of_backward:
     """``with side_stream_of_backward(tensors...) as on:`` -- inside a backward function: runs the body on the side
     stream of the current (device, stream) when the switch is on (``on`` tells), after making it wait for the current
@@ -622,14 +656,17 @@ class side_stream_of_backward:
         side.wait_stream(cur)
         for t in self.tensors:
             t.record_stream(side)
-        global side_stream_launches
+        global side_stream_launches, _on_side_stream
         side_stream_launches += 1
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
+        _on_side_stream = side
         return True
 
     def __exit__(self, *exc):
+        global _on_side_stream
         if self.ctx is not None:
+            _on_side_stream = None
             self.ctx.__exit__(*exc)
         return False
 

@@ -156,6 +156,15 @@ int bm_gemm_nt_h2_rows(const float* a, long a_sstride, long a_rstride, const flo
                        const float* x, long x_sstride, long x_rstride, const float* x_amax, float* part, int S,
                        int M, int Cn, int T, int KS, int dil, int nsplit, void* stream);
 
+/* Grouped form (KS = 1): group g contracts the segments order[seg[g] .. seg[g + 1]) (order nullable = identity; seg [G + 1]),
+ * part[g][split][m][c] -- the per-(layout, subject) weight gradient of the composed front end and the per-subject
+ * gradient of SubjectLayers (bm/models/common.py:55-58 backward).  bm_gemm_nt_h2_covers(..., G, dil, ordered) tells
+ * whether a shape is covered; bm_gemm_nt_h2_suggest_splits_grouped the splits per group. */
+int bm_gemm_nt_h2_grouped(const float* a, long a_sstride, long a_rstride, const float* a_amax, const float* x,
+                          long x_sstride, long x_rstride, const float* x_amax, const int* order, const int* seg,
+                          float* part, int S, int G, int M, int Cn, int T, int nsplit, void* stream);
+int bm_gemm_nt_h2_suggest_splits_grouped(int M, int Cn, int KS, int S, int T, int G);
+
 /* ClipLoss score contraction in compute mode "f16x2" (bm/losses.py:94, torch.einsum("bct,oct,o->bo") before the
  * candidate norms): part[split][b][o] = sum over the split's share of k of est[b][k] * cand[o][k]; est [B][K] and
  * cand [Bc][K] dense fp32, K = F * T; est_amax / cand_amax as for bm_gemm_nt_h2.  256 candidates x 256 (long K) or 128

@@ -510,3 +510,40 @@ def test_operand_spanning_2gb_takes_the_64bit_path(h2_mode, H):
     part = H.gemm_nt_partials(a.cuda(), big, 1, M, Cn, T, (0, T), (0, stride))
     ref = a.double() @ rows.double().t()
     assert rel_l2(part.sum(0), ref) < FWD_TOL
+
+
+@pytest.mark.parametrize("M,Cn,T,B,G", [(270, 208, 360, 96, 7),      # composed front end: taken with the operands swapped (256 x 128 tiles)
+                                        (320, 192, 192, 64, 3),      # 320 x 192 tiles as given
+                                        (45, 37, 120, 9, 4)])        # too small: narrow kernels, same contract
+def test_grouped_weight_gradient_on_the_wide_kernels(h2_mode, H, M, Cn, T, B, G):
+    """out[g][m][c] = sum over the segments of group g and t of a[s][m][t] x[s][c][t] (the per-(layout, subject) weight
+    gradient of the composed front end, bm/models/common.py:55-58 + :355-358 backward) on the wide f16x2 tiles: groups
+    through order / seg (one of them EMPTY), several splits per group, arbitrary output strides."""
+    g = _gen(M + Cn + G)
+    a = torch.randn(B, M, T, generator=g, dtype=torch.float64)
+    x = torch.randn(B, Cn, T, generator=g, dtype=torch.float64)
+    idx = torch.randint(0, G - 1, (B,), generator=g)           # group G - 1 stays empty
+    ref = torch.zeros(G, M, Cn, dtype=torch.float64)
+    for b in range(B):
+        ref[idx[b]] += a[b] @ x[b].t()
+    order, seg = H.group_by_index(idx.cuda(), G)
+    ag, xg = a.float().cuda(), x.float().cuda()
+    labels = []
+    timer = H.KernelTimer()
+    H.set_kernel_timer(timer)
+    try:
+        out = H.gemm_nt(ag, xg, B, M, Cn, T, 1, 1, order=order, seg=seg, G=G)
+        # the composed front end's layout: [G][M][Cn + 1] with the last column left alone
+        aug = torch.full((G, M, Cn + 1), 7.0, device="cuda")
+        H.gemm_nt(ag, xg, B, M, Cn, T, 1, 1, order=order, seg=seg, G=G, out=aug,
+                  out_strides=(M * (Cn + 1), Cn + 1, 1, 0))
+    finally:
+        H.set_kernel_timer(None)
+        labels = sorted({r[0] for r in timer.records})
+    assert rel_l2(out.view(G, M, Cn), ref) < GRAD_TOL, rel_l2(out.view(G, M, Cn), ref)
+    assert float(out.view(G, M, Cn)[G - 1].abs().max()) == 0.0
+    assert rel_l2(aug[:, :, :Cn], ref) < GRAD_TOL and bool((aug[:, :, Cn] == 7.0).all())
+    wide = bool(H.lib().bm_gemm_nt_h2_covers(M, Cn, 1, B, T, G, 1, 1)) or \
+        bool(H.lib().bm_gemm_nt_h2_covers(Cn, M, 1, B, T, G, 1, 1))
+    assert wide == (M >= 200), (M, wide)
+    assert all(("_h2w" in lb) == wide for lb in labels), labels

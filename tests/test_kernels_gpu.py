@@ -287,7 +287,7 @@ def test_clip_loss_at_the_whole_node_shape(H):
     cand = torch.randn(Bc, Fd, T, generator=g)
     est.data += 0.4 * cand[off:off + B]                       # planted: a non-trivial softmax
     valid = torch.ones(Bc)
-    masked = [3, 300, 301, 1500, 2047]
+    masked = [3, 300, 301, 1500, 1791]        # (none inside the target block 1792 .. 2047)
     valid[masked] = 0
     kept = torch.tensor([i for i in range(Bc) if i not in masked and not off <= i < off + B])
     cand_ref = torch.cat([cand[off:off + B], cand[kept]])     # bm/losses.py:105-111: the first B candidates are the targets

@@ -304,14 +304,21 @@ def test_out_of_range_subject_index_raises_like_the_reference_gather():
     solver.train_step(sb)                              # flag was cleared
 
 
-def test_node_negatives_refuse_per_rank_rejection():
+def test_node_negatives_accept_per_rank_rejection_with_constant_candidates():
+    """Whole-node negatives next to a ScaleReject that can reject (round 4: equal blocks of the nominal batch size,
+    padding rows masked -- test_replicas_with_per_rank_rejection_and_whole_node_negatives); still refused with a
+    LEARNABLE feature model, whose autograd-aware gather needs equal blocks of real candidates."""
     from brainmagick_amd.solver import Solver
+    from brainmagick_amd.models import DeepMel
     from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
     model, cfg = _small_model()
     scaler = DeviceBatchScaler(torch.zeros(2, 20), torch.ones(2, 20))
+    assert Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=False))._ragged_node
+    assert not Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=True))._ragged_node
+    fm = DeepMel(10, 8, 2, 10, kernel=3, stride=1, dilation_growth=2, dilation_period=5, batch_norm=True,
+                 activation_on_last=False, skip=True, glu_context=1, glu=2)
     with pytest.raises(ValueError):
-        Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=False))
-    Solver(model, negatives="node", scale_reject=ScaleReject(scaler, limit=16, clip=True))
+        Solver(model, negatives="node", feature_model=fm, scale_reject=ScaleReject(scaler, limit=16, clip=False))
 
 
 def test_flat_adam_is_a_torch_optimizer_and_checkpoints_round_trip():
