@@ -59,14 +59,13 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0     # dense bf16 / f16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # MFMA products per fp32-accurate block of each compute mode -> fp32-equivalent peak = 16-bit peak / products
 MODE_PEAK_TFLOPS = {"f32": PEAK_FP32_MFMA_TFLOPS, "f32x3": PEAK_16BIT_MFMA_TFLOPS / 6.0,
-                    "f16x2": PEAK_16BIT_MFMA_TFLOPS / 3.0, "bf16": PEAK_16BIT_MFMA_TFLOPS}
+                    "f16x2": PEAK_16BIT_MFMA_TFLOPS / 3.0}
 MODE_DTYPE = {
     "f16x2": "f32 (fp32-accurate: operands split into 2 scaled f16 planes, 3 MFMA products, fp32 accumulate; "
              "same parity tolerances as exact fp32, see DESIGN.md §2)",
     "f32x3": "f32 (fp32-accurate: operands split exactly into 3 bf16 planes, 6 MFMA products, "
              "fp32 accumulate; error vs fp64 <= exact-fp32 MFMA, see DESIGN.md §2)",
-    "f32": "f32 (exact-fp32 MFMA)",
-    "bf16": "bf16 operands, f32 accumulate (REDUCED precision, information only)"}
+    "f32": "f32 (exact-fp32 MFMA)"}
 
 
 def algorithmic_flops_per_segment(C, T, F, hidden=320, merger_ch=270) -> float:
@@ -510,7 +509,7 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=200)
     ap.add_argument("--dtype", default=hip_ops.DEFAULT_COMPUTE_DTYPE, choices=sorted(hip_ops.COMPUTE_DTYPES),
                     help="compute mode of the contractions; every fp32-class mode (f16x2, f32x3, f32) is held to the "
-                         "same parity tolerances; bf16 is opt-in REDUCED precision, for information only")
+                         "same parity tolerances")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -557,19 +556,11 @@ def main():
         # a throughput number of a diverged run is worthless (and flattering: the matrix pipe clocks higher on NaNs)
         raise SystemExit(f"bench: the training loss is not finite after the timed region ({final_loss})")
 
-    # The step as timed above runs its weight gradients on a second stream next to the data gradients (hip_ops
-    # side_stream_of_backward); a kernel's launch duration is only well defined when it has the chip to itself, so
-    # the per-launch HIP events (NOT part of `value`) are taken in a second pass over the same stream of batches with
-    # that overlap switched off -- and the single-stream step time is reported beside the headline.
-    side_stream_on = hip_ops._WGRAD_STREAM
-    hip_ops.set_wgrad_stream(False)
-    solver.train_step(stream.next()[0])
-    single_stream_elapsed, _ = timed_steps(args.steps)
+    # second pass over the same stream with per-launch HIP events (NOT part of `value`)
     timer = hip_ops.KernelTimer()
     hip_ops.set_kernel_timer(timer)
     event_pass_elapsed, _ = timed_steps(args.steps)
     hip_ops.set_kernel_timer(None)
-    hip_ops.set_wgrad_stream(side_stream_on)
     sustained = pcie = None
     if not args.no_side_blocks:
         # `value` comes from the driver's fixed --steps (0.3 s at 20 steps): the same loop over a longer window
@@ -638,12 +629,12 @@ def main():
                      # information: the same ratio against what a register-only MFMA loop on random 16-bit operands
                      # sustains on this chip (1 790 TF at a power-throttled ~1.75 GHz, scripts/micro/mfma_peak.hip)
                      "frac_of_sustained_mfma": (achieved / (peak_tf * 1790.0 / 2500.0)
-                                                if args.dtype in ("f16x2", "f32x3", "bf16") else None),
+                                                if args.dtype in ("f16x2", "f32x3") else None),
                      "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
                      "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                      "traffic_summary_avg_launch_ms": traffic_avg_ms,
-                     "events_taken": "single-stream pass (weight-gradient side stream off): a launch has the chip to itself",
+
                      "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,
                      "median_launch_ms": d["median_ms"],
                      "event_outliers_dropped": {k: v["outliers"] for k, v in ksum.items() if v["outliers"]},
@@ -655,10 +646,6 @@ def main():
                      "hbm_roofline_frac_step": step_bytes / (PEAK_HBM_GBS * 1e9) / (elapsed / args.steps),
                      "algorithmic_bytes_per_step": step_bytes},
     }
-    out["overlap"] = {"weight_gradients_on_side_stream": bool(side_stream_on),
-                      "single_stream_ms_per_step": single_stream_elapsed / args.steps * 1e3,
-                      "ms_per_step": elapsed / args.steps * 1e3,
-                      "side_stream_launches_total": hip_ops.side_stream_launches}
     out["sustained"] = sustained
     out["pcie_inclusive"] = pcie
     out["other_fp32_modes"] = other_modes or None

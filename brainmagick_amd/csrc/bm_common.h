@@ -25,6 +25,29 @@ int bm_check_launch(const char* what);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// n / d for 32-bit n by multiply-high (Granlund & Montgomery): the flat-index kernels split an element index into
+// (row, column) once per vector; a 64-bit hardware-less division there cost more instructions than the erf.
+struct BmFastDiv {
+    unsigned mul, shift, d;
+};
+static inline BmFastDiv bm_fastdiv(unsigned d) {
+    BmFastDiv f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                                  // l = ceil(log2 d)
+    f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    f.shift = l;
+    return f;
+}
+__host__ __device__ __forceinline__ unsigned bm_div(unsigned n, const BmFastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned t = __umulhi(n, f.mul);
+#else
+    const unsigned t = (unsigned)(((unsigned long long)n * f.mul) >> 32);
+#endif
+    return f.shift == 0 ? n : (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
 // Channel chunk of the packed-weight layout (see pack.hip / conv_nn.hip).
 #define BM_BKC 16
 // Wavefront width on CDNA.
@@ -55,8 +78,8 @@ __device__ __forceinline__ float bm_act(float z, int act, float leak) {
     return z;
 }
 
-// d/dz GELU(z) = Phi(z) + z phi(z) with ONE exponential and no erf (BM_ACT_GELU_FASTGRAD, the default of the
-// backward kernels; BM_GELU_GRAD_ERF=1 restores the erff + expf form below for A/B runs):
+// d/dz GELU(z) = Phi(z) + z phi(z) with ONE exponential and no erf (BM_ACT_GELU_FASTGRAD, what the backward kernels
+// use; the erff + expf form below serves the generic bm_act_grad):
 //     e = exp(-z^2 / 2),   Phi(-|z|) = e Q(t),  t = 1 / (1 + 0.24 |z|),
 // Q = degree-7 polynomial without constant term, fitted (scripts/fit_gelu_grad.py) to |e Q - Phi(-|z|)| <= 3.1e-10 on
 // [0, 14]; then  gelu'(z) = [z >= 0] + e (z / sqrt(2 pi)) -+ e Q.  ~14 VALU (2 transcendental) instead of ~45 with a
@@ -112,20 +135,16 @@ __device__ __forceinline__ double bm_wave_sum_d(double v) {
 #define BM_AMAX_SHARDS 8
 #define BM_AMAX_WS 16384
 __device__ __forceinline__ float bm_wave_max(float v);
-// Where a producer publishes max |output|:
-//   slot != null ("atomic" mode, BM_AMAX_ATOMIC=1): the BM_AMAX_SHARDS-float amax slot itself, ZEROED by the caller; the
-//     workgroup raises shard (workgroup id & 7) with one non-returning atomic max on the bit pattern (values are
-//     >= 0, so unsigned order = float order) -- and only if its maximum exceeds what the shard already holds, which
-//     after the first few workgroups is rare.  Order independent, hence deterministic; no follow-up launch.
-//   ws != null ("two-stage" mode, the default, and the stand-alone bm_amax pass): ws[workgroup id] = maximum,
-//     folded into the slot by the one-workgroup bm_amax_finalize launch.
+// Where a producer publishes max |output|: ws[workgroup id] = the workgroup's maximum (plain store), folded into the
+// tensor's amax slot by the one-workgroup bm_amax_finalize launch.  (Round 3 measured an atomic-max form that needs no
+// finalize launch: 0.26-0.33 ms per step SLOWER -- one agent-scope atomic per workgroup delays the retirement of the
+// 16 384-workgroup streaming kernels by more than the ~60 finalize launches cost; removed in round 4.)
 struct BmAmaxDst {
     float* ws;
-    float* slot;
 };
 __device__ __forceinline__ void bm_publish_amax_at(float m, const BmAmaxDst& dst, float* sh /* >= blockDim / 64 floats of LDS */,
                                                    unsigned wg /* index of the partial: workgroup or tile id */) {
-    if (!dst.ws && !dst.slot) return;                  // kernel argument: uniform
+    if (!dst.ws) return;                               // kernel argument: uniform
     m = bm_wave_max(m);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -133,14 +152,7 @@ __device__ __forceinline__ void bm_publish_amax_at(float m, const BmAmaxDst& dst
         const int nw = (blockDim.x + 63) >> 6;
         float v = sh[0];
         for (int w = 1; w < nw; ++w) v = fmaxf(v, sh[w]);
-        if (dst.slot) {
-            unsigned* p = reinterpret_cast<unsigned*>(dst.slot) + (wg & (BM_AMAX_SHARDS - 1));
-            const unsigned bits = __float_as_uint(v);
-            if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                (void)__hip_atomic_fetch_max(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            dst.ws[wg] = v;
-        }
+        dst.ws[wg] = v;
     }
 }
 __device__ __forceinline__ void bm_publish_amax(float m, const BmAmaxDst& dst, float* sh) {
@@ -148,7 +160,7 @@ __device__ __forceinline__ void bm_publish_amax(float m, const BmAmaxDst& dst, f
 }
 // plain-pointer form: two-stage mode into `ws`
 __device__ __forceinline__ void bm_publish_amax(float m, float* ws, float* sh) {
-    bm_publish_amax(m, BmAmaxDst{ws, nullptr}, sh);
+    bm_publish_amax(m, BmAmaxDst{ws}, sh);
 }
 __device__ __forceinline__ float bm_amax_load(const float* slot) {
     float m = slot[0];
@@ -163,11 +175,9 @@ int bm_amax_finalize_rows(const float* ws, int C, int nsplit, float* out, float*
 // host: the same launch also folds per-(channel, split) double sums [C][nsplit] into sums_out[C] (out must be non-null)
 int bm_amax_finalize_rows_sums(const float* ws, int C, int nsplit, float* out, float* rows_out,
                                const double* sum_partial, float* sums_out, hipStream_t stream);
-// host: destination of a producer's maximum for the current mode, and what follows its launch
-int bm_amax_atomic();                                   // 1 only with BM_AMAX_ATOMIC=1 (measured slower, core.hip)
+// host: destination of a producer's maximum, and what follows its launch
 static inline BmAmaxDst bm_amax_dst(float* amax_out, float* amax_ws) {
-    if (!amax_out) return BmAmaxDst{nullptr, nullptr};
-    return bm_amax_atomic() ? BmAmaxDst{nullptr, amax_out} : BmAmaxDst{amax_ws, nullptr};
+    return BmAmaxDst{amax_out ? amax_ws : nullptr};
 }
 static inline int bm_amax_done(const BmAmaxDst& d, int nblocks, float* amax_out, hipStream_t stream) {
     return d.ws ? bm_amax_finalize(d.ws, nblocks, amax_out, stream) : BM_OK;

@@ -37,7 +37,7 @@ struct ConvH2Args {
     ConvNNArgs c;
     const float* x_amax;      // [BM_AMAX_SHARDS] shards whose maximum bounds |x| of the input tensor, device memory
     const float* wscale;      // [G][Mpad] inverse row scales written by bm_pack_weights_h2
-    BmAmaxDst y_amax;         // where max |y_out| goes (bm_publish_amax): the zeroed slot, or per-workgroup partials
+    BmAmaxDst y_amax;         // where max |y_out| goes (bm_publish_amax): per-workgroup partials
 };
 
 // Power-of-two scale s with amax * s in [2^14, 2^15), and its exact inverse.  amax == 0 / subnormal / inf /
@@ -563,15 +563,6 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-static int h2_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("BM_H2_WIDE");      // BM_H2_WIDE=0: everything through the 3 x bf16 kernels
-        on = !(e && e[0] == '0');
-    }
-    return on;
-}
-
 // rows per wavefront-row block: the workgroup tile is 64 MW rows; MW in {5, 4, 2} minimising the padded rows
 // (ties -> the larger tile)
 extern "C" int bm_conv_h2_mw_for(int M) {
@@ -593,7 +584,7 @@ extern "C" int bm_conv_h2_mpad(int M) {
 // 1 when the wide f16x2 kernel covers this conv shape (otherwise the caller packs for / launches the 3 x bf16
 // kernels of conv_nn_x3.hip, which are fp32-accurate as well)
 extern "C" int bm_conv_h2_covers(int Cin, int M, int T, int KS, int dil) {
-    if (!h2_enabled() || (KS != 1 && KS != 3)) return 0;
+    if (KS != 1 && KS != 3) return 0;
     if ((KS >> 1) * dil > 16 || T <= 128) return 0;
     if ((long)Cin * T * 4 >= 0x40000000L) return 0;
     if ((long)Cin * KS > 3840) return 0;              // PACK_MAX_NK: a weight row must fit the packing kernel's LDS tile
@@ -833,10 +824,10 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
     args.c.ntiles_m = args.c.Mpad / HBM;
     const long nblocks = (long)args.c.B * args.c.ntiles_n * args.c.ntiles_m;
     if (nblocks <= 0) return BM_OK;
-    // two-stage mode: the workspace bounds the grid (atomic mode has no such limit)
-    const bool publish = y_amax_out && (args.y_amax.slot || (args.y_amax.ws && nblocks <= BM_AMAX_WS));
+    // the workspace bounds the grid
+    const bool publish = y_amax_out && args.y_amax.ws && nblocks <= BM_AMAX_WS;
     float* ws = args.y_amax.ws;
-    if (!publish) args.y_amax = BmAmaxDst{nullptr, nullptr};
+    if (!publish) args.y_amax = BmAmaxDst{nullptr};
     hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
     if (int rc = bm_check_launch("conv_nn_h2w")) return rc;
     if (publish) return bm_amax_done(args.y_amax, (int)nblocks, y_amax_out, stream);

@@ -10,7 +10,7 @@
 // (brainmagick_amd.set_compute_dtype("f32x3")); activations, parameters, gradients and every
 // elementwise kernel stay fp32.
 //
-// Structure = conv_nn_bf16.hip with three operand planes:
+// Three operand planes:
 //   packed weights  [g][chunk of 32 ch][tap][plane][4 groups][Mpad][8 ch] bf16  (bm_pack_weights_x3)
 //   LDS A slab      [plane][4 groups][BM] x 16 B,   LDS x window  [plane][4 groups][XW] x 16 B
 // stage = (chunk, tap): 2 k16-steps x 6 terms x MT MFMAs.  LDS is single-buffered (two barriers per
@@ -205,13 +205,25 @@ static int launch_conv_nn_x3(const ConvNNArgs& a, hipStream_t stream) {
     return bm_check_launch("conv_nn_x3");
 }
 
-int bm_conv_nn_x3w_try(const ConvNNArgs& a, hipStream_t stream);   // conv_nn_x3w.hip
-extern "C" int bm_conv_bf16_mt_for(int M);
-extern "C" int bm_conv_bf16_mpad(int M);
+// Tile heights of the narrow kernels: 3, 4 or 5 MFMA row blocks (96 / 128 / 160 rows), whichever pads M least.
+extern "C" int bm_conv_x3_mt_for(int M) {
+    int best = 3;
+    long best_cost = -1;
+    for (int mt = 3; mt <= 5; ++mt) {
+        const long bm = 32L * mt;
+        const long cost = (long)cdiv(M, bm) * bm * 16 - mt;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt; }
+    }
+    return best;
+}
+extern "C" int bm_conv_x3_mpad(int M) {
+    const int mt = bm_conv_x3_mt_for(M);
+    return cdiv(M, 32 * mt) * 32 * mt;
+}
 
 // number of bf16 elements of the packed 3-plane weight buffer
 extern "C" long bm_packed_weight_elems_x3(int G, int M, int Cin, int KS) {
-    return (long)G * cdiv(Cin, XC) * KS * 3 * XG * bm_conv_bf16_mpad(M) * 8;
+    return (long)G * cdiv(Cin, XC) * KS * 3 * XG * bm_conv_x3_mpad(M) * 8;
 }
 
 // dst[g][chunk][tap][plane][kg][Mpad][8] (bf16) <- exact 3-way split of alpha * src[...]
@@ -253,7 +265,7 @@ extern "C" int bm_pack_weights_x3(const float* src, void* dst, int G, int M, int
                                   void* stream) {
     BM_REQUIRE(src && dst, "pack_weights_x3: null pointer");
     BM_REQUIRE(G > 0 && M > 0 && Cin > 0 && KS > 0, "pack_weights_x3: bad dims");
-    const int Mpad = bm_conv_bf16_mpad(M);
+    const int Mpad = bm_conv_x3_mpad(M);
     const int nchunk = cdiv(Cin, XC);
     const long total = (long)G * nchunk * KS * XG * Mpad * 8;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
@@ -278,17 +290,12 @@ extern "C" int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpack
     a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.res = res; a.res_bstride = res_bstride;
     a.y_pre = y_pre; a.y_out = y_out; a.y_bstride = y_bstride; a.stats = stats;
     a.B = B; a.Cin = Cin; a.M = M; a.T = T; a.KS = KS; a.dil = dil; a.act = act; a.leak = leak;
-    const int mt = bm_conv_bf16_mt_for(M);
-    a.Mpad = bm_conv_bf16_mpad(M);
+    const int mt = bm_conv_x3_mt_for(M);
+    a.Mpad = bm_conv_x3_mpad(M);
     a.nchunk = cdiv(Cin, XC);
     a.ntiles_n = cdiv(T, 128);
     a.ntiles_m = a.Mpad / (32 * mt);
     hipStream_t s = (hipStream_t)stream;
-    // large layers (M a multiple of 320): wide-tile kernel of conv_nn_x3w.hip
-    {
-        const int rc = bm_conv_nn_x3w_try(a, s);
-        if (rc >= 0) return rc;
-    }
 #define DISPATCH_KS(MT_)                                                  \
     switch (KS) {                                                         \
         case 1: return launch_conv_nn_x3<MT_, 1>(a, s);                   \

@@ -99,18 +99,3 @@ int bm_amax_finalize_rows_sums(const float* ws, int C, int nsplit, float* out, f
 }
 
 extern "C" int bm_amax_ws_elems(void) { return BM_AMAX_WS; }
-
-// Producers store per-workgroup partial maxima that a one-workgroup finalize launch folds (default), or raise a
-// pre-zeroed amax slot with atomic max (BM_AMAX_ATOMIC=1).  Measured on the cfg2 step, same box, interleaved
-// (profiles/r3_ab_notes.md): the atomic form removes ~60 finalize launches per step and is nevertheless 0.26-0.33 ms
-// per step SLOWER -- the agent-scope load + atomic at the end of every workgroup delay its retirement in the
-// 16 384-workgroup streaming kernels by more than the 4.7 us launches cost.
-int bm_amax_atomic() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("BM_AMAX_ATOMIC");
-        on = (e && e[0] == '1');
-    }
-    return on;
-}
-extern "C" int bm_amax_is_atomic(void) { return bm_amax_atomic(); }

@@ -587,28 +587,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #endif
 }
 
-// BM_GEMM_FLAT_AXIS=0: per-segment stages also where the flat walk applies (A/B switch)
-static int hg_flat_axis() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("BM_GEMM_FLAT_AXIS");
-        on = !(e && e[0] == '0');
-    }
-    return on;
-}
-
 // tile family of a shape: 0 = not covered, 1 = 320 x 192 (<KS,5,3>), 2 = 256 x 128 (<1,4,2>)
 static int hg_family(int S, int G, int M, int Cn, int T, int KS, int dil, bool ordered) {
-    static int wide = -1, grouped = -1;
-    if (wide < 0) {
-        const char* e = getenv("BM_H2_WIDE");          // BM_H2_WIDE=0: A/B runs against the 3 x bf16 kernels
-        wide = !(e && e[0] == '0');
-        const char* e2 = getenv("BM_H2_GROUPED");      // BM_H2_GROUPED=0: grouped contractions on the narrow kernels (A/B)
-        grouped = !(e2 && e2[0] == '0');
-    }
-    if (!wide || (KS != 3 && KS != 1)) return 0;
+    if (KS != 3 && KS != 1) return 0;
     // grouped (order / seg) contractions: the 1x1 tile families, per-segment walk, per-tensor scales
-    if ((G != 1 || ordered) && (!grouped || KS != 1)) return 0;
+    if ((G != 1 || ordered) && KS != 1) return 0;
     if (dil < 1 || dil > 32 || T < 2 * HG_K) return 0;
     if ((long)S * ((T + HG_K - 1) / HG_K) < 32L * G) return 0;
     // padded rows / columns are wasted MFMA work: at most 25 % (3 taps) / 50 % (1x1 layers, small in absolute terms)
@@ -693,7 +676,7 @@ static int gemm_nt_h2_impl(const float* a, long a_sstride, long a_rstride, const
     const bool rs = a_row_amax && fam == 1 && T % 4 == 0 && a_rstride % 4 == 0 && a_sstride % 4 == 0;
     // flat time axis (no per-segment padding of T to a multiple of 32): row-scaled 3-tap weight gradients whose
     // tensors fit one 2 GB descriptor each
-    const bool flat = rs && KS == 3 && hg_flat_axis() && T % HG_K != 0 && T >= 2 * HG_K && S > 1 &&
+    const bool flat = rs && KS == 3 && T % HG_K != 0 && T >= 2 * HG_K && S > 1 &&
                       ((long)(S - 1) * a_sstride + (long)(M - 1) * a_rstride + T) * 4 < 0x7f000000L &&
                       ((long)(S - 1) * x_sstride + (long)(Cn - 1) * x_rstride + T) * 4 < 0x7f000000L &&
                       a_sstride >= T && x_sstride >= T && x_sstride % 4 == 0;
@@ -748,12 +731,7 @@ static int clip_scores_wide(int B, int Bc, long K) {
 }
 
 extern "C" int bm_clip_scores_h2_covers(int B, int Bc, long K) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("BM_CLIP_SCORES_KERNEL");      // BM_CLIP_SCORES_KERNEL=0: the generic bm_gemm_nt_h2 tiles (A/B switch)
-        on = !(e && e[0] == '0');
-    }
-    if (!on || B <= 0 || Bc <= 0 || Bc % 4 != 0 || K < 16 * HG_K || K >= 0x7fffffffL) return 0;
+    if (B <= 0 || Bc <= 0 || Bc % 4 != 0 || K < 16 * HG_K || K >= 0x7fffffffL) return 0;
     if (((long)(Bc - 1) * K + K) * 4 >= 0x7f000000L || ((long)(B - 1) * K + K) * 4 >= 0x7f000000L) return 0;
     // padded rows / columns are wasted MFMA work
     const int bc = clip_scores_wide(B, Bc, K) ? 256 : 128;

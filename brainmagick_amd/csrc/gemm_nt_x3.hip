@@ -286,10 +286,6 @@ static int launch_gemm_nt_x3(GemmNTArgsX a, hipStream_t stream) {
     return bm_check_launch("gemm_nt_x3");
 }
 
-int bm_gemm_nt_x3w_try(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
-                       long x_rstride, const int* order, float* part, int S, int G, int M, int Cn, int T,
-                       int KS, int dil, int nsplit, hipStream_t stream);   // gemm_nt_x3w.hip
-
 extern "C" int bm_gemm_nt(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                           long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                           int Cn, int T, int KS, int dil, int nsplit, void* stream);   // gemm_nt.hip
@@ -316,11 +312,6 @@ extern "C" int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, con
     g.order = order; g.seg = seg; g.part = part;
     g.S = S; g.M = M; g.Cn = Cn; g.T = T; g.dil = dil; g.nsplit = nsplit; g.G = G;
     hipStream_t s = (hipStream_t)stream;
-    if (!seg) {      // weight gradients of the big layers: wide-tile kernel of gemm_nt_x3w.hip
-        const int rc = bm_gemm_nt_x3w_try(a, a_sstride, a_rstride, x, x_sstride, x_rstride, order, part, S, G, M,
-                                          Cn, T, KS, dil, nsplit, s);
-        if (rc >= 0) return rc;
-    }
     const bool bigM = prefer_big_x(M);
     if (KS == 1) {
         const bool bigC = prefer_big_x(Cn);

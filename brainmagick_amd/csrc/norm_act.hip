@@ -155,14 +155,13 @@ template <int VEC>
 __global__ void affine_act_res_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                       const float* __restrict__ shift, const float* __restrict__ res,
                                       float* __restrict__ out, long nvec, int C, int T, int act,
-                                      float leak, BmAmaxDst amax_ws) {
+                                      float leak, BmAmaxDst amax_ws, BmFastDiv div_tv, BmFastDiv div_c) {
     __shared__ float amax_sh[4];
-    const int TV = T / VEC;
     float amx = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec;
          e += (long)gridDim.x * blockDim.x) {
-        const long row = e / TV;
-        const int c = (int)(row % C);
+        const unsigned row = bm_div((unsigned)e, div_tv);           // nvec < 2^32 (host check)
+        const int c = (int)(row - bm_div(row, div_c) * (unsigned)C);
         const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
         Pack<VEC> v = Pack<VEC>::ld(y + e * VEC);
         Pack<VEC> r;
@@ -186,6 +185,7 @@ extern "C" int bm_affine_act_res(const float* y, const float* scale, const float
     BM_REQUIRE(!amax_out || amax_ws, "affine_act_res: amax_out needs the amax workspace");
     const long n = (long)B * C * T;
     if (n == 0) return BM_OK;
+    BM_REQUIRE(n < 0xffffffffL, "affine_act_res: tensor of %ld elements (32-bit element index)", n);
     hipStream_t s = (hipStream_t)stream;
     const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     int nblk = 0;
@@ -193,12 +193,12 @@ extern "C" int bm_affine_act_res(const float* y, const float* scale, const float
         const long nvec = n / 4;
         const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
         hipLaunchKernelGGL(affine_act_res_kernel<4>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
-                           out, nvec, C, T, act, leak, amax_dst);
+                           out, nvec, C, T, act, leak, amax_dst, bm_fastdiv((unsigned)(T / 4)), bm_fastdiv((unsigned)C));
         nblk = blocks;
     } else {
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
         hipLaunchKernelGGL(affine_act_res_kernel<1>, dim3(blocks), dim3(256), 0, s, y, scale, shift, res,
-                           out, n, C, T, act, leak, amax_dst);
+                           out, n, C, T, act, leak, amax_dst, bm_fastdiv((unsigned)T), bm_fastdiv((unsigned)C));
         nblk = blocks;
     }
     if (int rc = bm_check_launch("affine_act_res")) return rc;
@@ -318,25 +318,10 @@ __global__ void finalize_channel_sums_kernel(const double* __restrict__ partial,
 
 extern "C" int bm_bwd_nsplit(int B) { return B >= 64 ? 8 : (B >= 8 ? 4 : 1); }
 
-// BM_GELU_GRAD_ERF=1: the GELU derivative through erff + expf (A/B switch; default = bm_gelu_grad_fast)
-static int gelu_grad_code(int act) {
-    static int erf_form = -1;
-    if (erf_form < 0) {
-        const char* e = getenv("BM_GELU_GRAD_ERF");
-        erf_form = (e && e[0] == '1');
-    }
-    return (act == BM_ACT_GELU && !erf_form) ? BM_ACT_GELU_FASTGRAD : act;
-}
-
-// BM_BN_APPLY_REVERSE=0: the apply pass walks the batch in the same order as the reduce pass (A/B switch)
-static int bn_apply_reverse() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("BM_BN_APPLY_REVERSE");
-        on = !(e && e[0] == '0');
-    }
-    return on;
-}
+// The backward kernels evaluate the GELU derivative with one exponential and no erf (bm_gelu_grad_fast, bm_common.h);
+// the apply pass walks the batch in the OPPOSITE order of the reduce pass (what that pass read last is what the
+// memory-side cache still holds; -0.03 ms per step, profiles/r3r_ab_bn_apply_reverse.txt).
+static int gelu_grad_code(int act) { return act == BM_ACT_GELU ? BM_ACT_GELU_FASTGRAD : act; }
 
 // workspace: doubles, (2*C*nsplit) for the reduce partials + (C*nsplit) for the dy sums.
 extern "C" long bm_act_bn_bwd_workspace_bytes(int B, int C) {
@@ -370,14 +355,14 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
-                           amax_dst, bn_apply_reverse());
+                           amax_dst, 1);
     } else {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                            invstd, partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, act, leak,
-                           amax_dst, bn_apply_reverse());
+                           amax_dst, 1);
     }
     // the (channel, split) grid's partials are per channel already: ONE launch folds them into the tensor slot, the
     // per-channel maxima and the bias gradient (two-stage mode; otherwise the sums get their own launch)
@@ -513,15 +498,13 @@ extern "C" int bm_channel_stats(const float* x, float* stats, int B, int C, int 
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ void glu_fwd_kernel(const float* __restrict__ u, float* __restrict__ out, long nvec, int H,
-                               int T, BmAmaxDst amax_ws) {
+                               int T, BmAmaxDst amax_ws, BmFastDiv div_per) {
     __shared__ float amax_sh[4];
-    const int TV = T / VEC;
     float amx = 0.f;
-    const long per = (long)H * TV;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nvec;
          e += (long)gridDim.x * blockDim.x) {
-        const long b = e / per;
-        const long r = e - b * per;
+        const long b = bm_div((unsigned)e, div_per);                // nvec < 2^32 (host check); per = H * TV
+        const long r = e - b * (long)div_per.d;
         const float* ua = u + (b * 2 * H) * T + r * VEC;
         const Pack<VEC> a = Pack<VEC>::ld(ua), g = Pack<VEC>::ld(ua + (long)H * T);
         Pack<VEC> o;
@@ -541,17 +524,20 @@ extern "C" int bm_glu_fwd(const float* u, float* out, int B, int H, int T, float
     BM_REQUIRE(!amax_out || amax_ws, "glu_fwd: amax_out needs the amax workspace");
     const long n = (long)B * H * T;
     if (n == 0) return BM_OK;
+    BM_REQUIRE(n < 0xffffffffL && (long)H * T < 0xffffffffL, "glu_fwd: tensor of %ld elements (32-bit element index)", n);
     hipStream_t s = (hipStream_t)stream;
     const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     int nblk = 0;
     if (T % 4 == 0) {
         const long nvec = n / 4;
         const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
-        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T, amax_dst);
+        hipLaunchKernelGGL(glu_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, u, out, nvec, H, T, amax_dst,
+                           bm_fastdiv((unsigned)((long)H * (T / 4))));
         nblk = blocks;
     } else {
         const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
-        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T, amax_dst);
+        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, u, out, n, H, T, amax_dst,
+                           bm_fastdiv((unsigned)((long)H * T)));
         nblk = blocks;
     }
     if (int rc = bm_check_launch("glu_fwd")) return rc;

@@ -10,16 +10,7 @@ import torch
 
 from . import hip_ops as H
 
-import os
 
-# A/B switch (measurement only): BatchNorm partial statistics from the conv epilogue instead of the
-# separate streaming pass.
-_STATS_IN_EPILOGUE = os.environ.get("BM_STATS_IN_EPILOGUE", "0") == "1"
-# the wide f16x2 conv produces the BatchNorm partial sums in its epilogue (A/B switch: "0" = a channel_stats pass)
-_STATS_IN_EPILOGUE_H2 = os.environ.get("BM_STATS_IN_EPILOGUE_H2", "1") == "1"
-
-# A/B switch: the weight gradient of a ConvTranspose1d(k=1) with the input as the row operand (see _conv_weight_grads)
-_SWAP_TRANSPOSED_WGRAD = os.environ.get("BM_SWAP_TRANSPOSED_WGRAD", "1") == "1"
 
 ACT_CODES = {"none": H.ACT_NONE, "gelu": H.ACT_GELU, "relu": H.ACT_RELU, "leaky": H.ACT_LEAKY}
 
@@ -32,24 +23,15 @@ def _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight):
     """dW in the layout of the parameter: Conv1d [M,Cin,KS] or ConvTranspose1d(k=1) [Cin,M,1]; written straight into
     the optimizer's flat gradient bucket when the parameter has a registered destination (hip_ops.grad_destination)."""
     dst = H.grad_destination(weight)
-    # the contraction shares nothing but its inputs with the data gradient that follows: second stream (hip_ops)
-    with H.side_stream_of_backward(dy, x, dst):
-        return _conv_weight_grads_here(dy, x, weight, KS, dil, transposed_weight, dst)
-
-
-def _conv_weight_grads_here(dy, x, weight, KS, dil, transposed_weight, dst):
     B, M, T = dy.shape
     Cin = x.shape[1]
     # (a registered destination is returned as a FRESH view: autograd only adopts a gradient tensor nobody else holds)
     if transposed_weight:
         out = dst if dst is not None else torch.empty(weight.shape, device=dy.device, dtype=torch.float32)   # [Cin, M, 1]
-        if _SWAP_TRANSPOSED_WGRAD:
-            # dW[c][m] = sum x[c][t] dy[m][t]: with x as the ROW operand the result lands in the parameter's own
-            # [Cin, M] layout, and the head's 640 x 120 gradient fits the wide f16x2 tiles (640 rows x 128 / 192
-            # columns) instead of falling to the narrow kernels as 120 rows x 640 columns (0.13 -> ~0.07 ms per step)
-            H.gemm_nt(x, dy, B, Cin, M, T, 1, 1, out=out.view(1, Cin, M, 1))
-        else:
-            H.gemm_nt(dy, x, B, M, Cin, T, 1, 1, out=out, out_strides=(0, 1, M, 0))
+        # dW[c][m] = sum x[c][t] dy[m][t]: with x as the ROW operand the result lands in the parameter's own
+        # [Cin, M] layout, and the head's 640 x 120 gradient fits the wide f16x2 tiles (640 rows x 128 columns)
+        # instead of falling to the narrow kernels as 120 rows x 640 columns
+        H.gemm_nt(x, dy, B, Cin, M, T, 1, 1, out=out.view(1, Cin, M, 1))
         return out.view(weight.shape) if dst is not None else out
     if dst is not None:
         H.gemm_nt(dy, x, B, M, Cin, T, KS, dil, out=dst.view(1, M, Cin, KS))
@@ -98,8 +80,6 @@ class Conv1dFn(torch.autograd.Function):
             dy = dout
             if has_bias:
                 dbias = H.channel_sum(dy)
-        # (the weight gradient first: it is handed to the side stream at this point of the current one, and the data
-        # gradient enqueued behind it then runs NEXT TO it)
         dw = _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight) \
             if ctx.needs_input_grad[1] else None
         dx = None
@@ -134,7 +114,7 @@ class ConvBNActFn(torch.autograd.Function):
         res = x if residual else None
         needs_grad = x.requires_grad or weight.requires_grad
         if training:
-            if _STATS_IN_EPILOGUE or (_STATS_IN_EPILOGUE_H2 and getattr(wp, "_bm_mode", "") == "f16x2"):
+            if getattr(wp, "_bm_mode", "") == "f16x2":     # the wide f16x2 conv adds the partial sums in its epilogue
                 pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=bias, want_pre=True,
                                           want_out=False, want_stats=True)
             else:
@@ -159,7 +139,7 @@ class ConvBNActFn(torch.autograd.Function):
         M, Cin, _ = weight.shape
         dy, dgamma, dbeta, dbias = H.act_bn_bwd(dout, pre, scale, shift, mean, invstd, training, act,
                                                 leak, want_affine_grads=True, want_dbias=has_bias)
-        dw = _conv_weight_grads(dy, x, weight, KS, dil, False) if ctx.needs_input_grad[1] else None   # side stream
+        dw = _conv_weight_grads(dy, x, weight, KS, dil, False) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
             # dx feeds the previous layer's elementwise backward kernel: nobody needs its maximum
@@ -187,7 +167,7 @@ class GLUConvFn(torch.autograd.Function):
         x, weight, u = ctx.saved_tensors
         M, Cin, KS = weight.shape
         du, dbias = H.glu_bwd(_c(dout), u, want_dbias=ctx.has_bias)
-        dw = _conv_weight_grads(du, x, weight, KS, 1, False) if ctx.needs_input_grad[1] else None     # side stream
+        dw = _conv_weight_grads(du, x, weight, KS, 1, False) if ctx.needs_input_grad[1] else None  
         dx = None
         if ctx.needs_input_grad[0]:
             _, dx, _ = H.conv_nn(du, H.pack_conv_dgrad(weight, (du.shape[2], 1)), Cin, KS, 1, publish_amax=False)

@@ -24,12 +24,12 @@ BKC = 16
 #   "f32x3" fp32-ACCURATE contraction on the bf16 matrix cores: both fp32 operands are split
 #           EXACTLY into three bf16 planes, six partial products per block, fp32 accumulate; measured
 #           error vs fp64 <= the exact-fp32 MFMA path's, held to the same parity tolerances;
-#   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain;
-#   "bf16"  opt-in REDUCED precision: operands rounded to bf16, fp32 accumulate (tolerance 1e-2).
+#   "f32"   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-identical to an fp32 FMA chain.
+# (Round 4 removed the opt-in reduced-precision "bf16" mode and the wide-tile f32x3 kernels: every mode left is
+# fp32-class and held to the same tolerances.)
 import os as _os
-import threading as _threading
 DEFAULT_COMPUTE_DTYPE = "f16x2"
-COMPUTE_DTYPES = ("f32", "f32x3", "f16x2", "bf16")
+COMPUTE_DTYPES = ("f32", "f32x3", "f16x2")
 _compute_dtype = _os.environ.get("BM_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE)
 if _compute_dtype not in COMPUTE_DTYPES:
     raise ValueError(f"BM_COMPUTE_DTYPE must be one of {COMPUTE_DTYPES}, got {_compute_dtype!r}")
@@ -144,9 +144,6 @@ def amax(x: torch.Tensor, nonfinite_flag: tp.Optional[torch.Tensor] = None) -> t
     return out
 
 
-_NO_PUBLISH = _os.environ.get("BM_NO_AMAX_PUBLISH", "0") == "1"     # A/B switch: stand-alone amax passes instead
-_DIRECT_GRADS = _os.environ.get("BM_DIRECT_GRADS", "1") == "1"      # A/B switch: weight gradients written straight into the flat bucket
-_ROW_SCALES = _os.environ.get("BM_ROW_SCALES", "1") == "1"          # A/B switch: per-row scales of dy in the weight gradients
 _amax_pool: tp.Dict[torch.device, tp.List[tp.Any]] = {}
 _amax_workspaces: tp.Dict[tp.Any, torch.Tensor] = {}
 
@@ -165,7 +162,7 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
     """An [AMAX_SHARDS] fp32 slot for a producer kernel to publish max|t| into (f16x2 mode only; None otherwise).
     Slots are carved out of pooled buffers, each slot is used once.  The slot is attached to the tensor like
     `amax()` would, so the consuming contraction finds it without a pass over the tensor."""
-    if _compute_dtype != "f16x2" or _NO_PUBLISH or t.numel() == 0:      # empty: the producer returns before it writes
+    if _compute_dtype != "f16x2" or t.numel() == 0:      # empty: the producer returns before it writes
         return None
     pool = _amax_pool.get(t.device)
     if pool is None or pool[1] >= pool[0].numel():
@@ -182,7 +179,7 @@ def _row_amax_out(t: torch.Tensor, slot) -> tp.Optional[torch.Tensor]:
     tensor slot; two-stage amax mode only).  A gradient channel is a row of the weight gradient: the f16x2 weight-gradient
     kernel then scales A row by row (csrc/gemm_nt_h2w.hip, RS kernels), so a channel far below its tensor's maximum keeps
     its 22 bits.  Attached to the tensor like the slot."""
-    if slot is None or lib().bm_amax_is_atomic():
+    if slot is None:
         return None
     rows = torch.empty(t.shape[1], device=t.device, dtype=torch.float32)
     t._bm_row_amax = (t._version, t.data_ptr(), rows)
@@ -233,7 +230,6 @@ def share_amax(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
 # the parameters changed -- instead of one small launch per conv, forward and backward.  "Changed" = the
 # library's own writers said so (weights_changed(): FlatAdam.step, the data-parallel gathers) or the tensor's
 # autograd version moved (load_state_dict, in-place edits); evaluation never re-packs.
-_BATCH_PACK = _os.environ.get("BM_BATCH_PACK", "1") == "1"
 _weights_epoch = 0
 pack_launches = 0            # launches of either packing kernel (tests / bench bookkeeping)
 
@@ -323,7 +319,7 @@ def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, 
     mode = _compute_dtype
     if mode == "f16x2":
         if shape is not None and lib().bm_conv_h2_covers(Cin, M, shape[0], KS, shape[1]):
-            if alpha is None and src.requires_grad and src.is_leaf and _BATCH_PACK:
+            if alpha is None and src.requires_grad and src.is_leaf:
                 return _pack_plan(src.device).get(src, (G, M, Cin, KS, sg, sm, sc, sj, int(flip)))
             nbytes = lib().bm_packed_weight_bytes_h2(G, M, Cin, KS)
             dst = torch.empty(nbytes, device=src.device, dtype=torch.uint8)
@@ -335,13 +331,11 @@ def pack_weights(src: torch.Tensor, G: int, M: int, Cin: int, KS: int, sg: int, 
             dst._bm_groups = G
             return dst
         mode = "f32x3"
-    if mode in ("bf16", "f32x3"):
-        x3 = mode == "f32x3"
-        n = (lib().bm_packed_weight_elems_x3 if x3 else lib().bm_packed_weight_elems_bf16)(G, M, Cin, KS)
+    if mode == "f32x3":
+        n = lib().bm_packed_weight_elems_x3(G, M, Cin, KS)
         dst = torch.empty(n, device=src.device, dtype=torch.bfloat16)
-        fn = lib().bm_pack_weights_x3 if x3 else lib().bm_pack_weights_bf16
-        check(fn(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip), _p(_opt(alpha, "alpha")),
-                 _stream()), "bm_pack_weights_x3" if x3 else "bm_pack_weights_bf16")
+        check(lib().bm_pack_weights_x3(_p(src), _p(dst), G, M, Cin, KS, sg, sm, sc, sj, int(flip),
+                                       _p(_opt(alpha, "alpha")), _stream()), "bm_pack_weights_x3")
         dst._bm_mode = mode                      # tells conv_nn which kernel family packed it
         return dst
     n = lib().bm_packed_weight_elems(G, M, Cin, KS)
@@ -406,8 +400,7 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
             check(lib().bm_conv1d_nn_h2(_p(x), Cin * T, _p(x_amax), _p(wpacked), *common, wpacked._bm_groups,
                                         *_slot_args(y_slot), _stream()), "bm_conv1d_nn_h2")
     else:
-        fn = {"f32": lib().bm_conv1d_nn, "bf16": lib().bm_conv1d_nn_bf16,
-              "f32x3": lib().bm_conv1d_nn_x3}[mode]
+        fn = {"f32": lib().bm_conv1d_nn, "f32x3": lib().bm_conv1d_nn_x3}[mode]
 
         def launch():
             check(fn(_p(x), Cin * T, _p(wpacked), *common, _stream()), f"bm_conv1d_nn[{mode}]")
@@ -416,10 +409,7 @@ def conv_nn(x: torch.Tensor, wpacked: torch.Tensor, M: int, KS: int = 1, dil: in
             label = f"conv_nn_h2w_kernel<{KS},{lib().bm_conv_h2_mw_for(M)}>"
         else:
             label = {"f32": f"conv_nn_kernel<{lib().bm_conv_mt_for(M)}>",
-                     "bf16": f"conv_nn_bf16_kernel<{lib().bm_conv_bf16_mt_for(M)}>",
-                     "f32x3": (f"conv_nn_x3w_kernel<{KS}>"
-                               if mode == "f32x3" and lib().bm_conv_x3_is_wide(Cin, M, T, KS, dil, int(want_stats))
-                               else f"conv_nn_x3_kernel<{lib().bm_conv_bf16_mt_for(M)}>")}[mode]
+                     "f32x3": f"conv_nn_x3_kernel<{lib().bm_conv_x3_mt_for(M)}>"}[mode]
         _timer.launch(label, 2.0 * B * T * M * Cin * KS, launch)
     else:
         launch()
@@ -485,8 +475,7 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
             force_f32: bool = False):
     """out[g*sg + m*sm + c*sc + j*sj] = sum_{s in g} sum_t a[s][m][t] * x[s][c][t + shift_j].
 
-    In bf16 compute mode the weight-gradient contractions use bf16-rounded operands; callers whose
-    result feeds a softmax (merger logits, ClipLoss scores) pass ``force_f32``.
+    (``force_f32`` is kept in the signature for callers whose result feeds a softmax: every mode left is fp32-class.)
 
     a_strides / x_strides = (segment stride, row stride) in elements; defaults are contiguous
     [S][rows][T].  Default ``out`` is [G][M][Cn][KS] contiguous."""
@@ -500,7 +489,7 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         out_strides = (M * Cn * KS, Cn * KS, KS, 1)
     if out is None:
         out = torch.empty(G, M, Cn, KS, device=a.device, dtype=torch.float32)
-    mode = "f32" if (force_f32 and _compute_dtype == "bf16") else _compute_dtype
+    mode = _compute_dtype
     grouped = order is not None or seg is not None
     if mode == "f16x2":
         # rows T apart; the segment stride only matters when there is more than one segment
@@ -519,10 +508,7 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         elif nsplit is None:
             nsplit = lib().bm_gemm_nt_h2_suggest_splits_grouped(M, Cn, KS, S, T, G)
     if nsplit is None:
-        if mode == "f32x3" and order is None:
-            nsplit = lib().bm_gemm_nt_x3_suggest_splits(M, Cn, KS, S, T, G, dil)
-        else:
-            nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G)
+        nsplit = lib().bm_gemm_nt_suggest_splits(M, Cn, KS, S, T, G)
         if G > 1:
             # grouped (per-subject / per-layout) weight gradients run in the 160 x 128-tile kernels, two workgroups
             # per CU: split each group's (segment, 32-sample chunk) list until ~512 workgroups exist, keeping at
@@ -537,7 +523,7 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         part = torch.empty(G * nsplit * M * Cn * KS, device=a.device, dtype=torch.float32)
     if mode == "f16x2":
         a_amax, x_amax = amax(a), amax(x)
-        a_rows = row_amax_of(a) if _ROW_SCALES else None       # published by the producer of `a` (act_bn_bwd / glu_bwd)
+        a_rows = row_amax_of(a)          # published by the producer of `a` (act_bn_bwd / glu_bwd)
         if a_rows is not None and a_rows.numel() != M:
             a_rows = None
 
@@ -552,18 +538,14 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
                                            x_strides[0], x_strides[1], _p(x_amax), _p(part), S, M, Cn, T, KS, dil,
                                            nsplit, _stream()), "bm_gemm_nt_h2")
     else:
-        fn = {"f32": lib().bm_gemm_nt, "bf16": lib().bm_gemm_nt_bf16, "f32x3": lib().bm_gemm_nt_x3}[mode]
+        fn = {"f32": lib().bm_gemm_nt, "f32x3": lib().bm_gemm_nt_x3}[mode]
 
         def launch():
             check(fn(_p(a), a_strides[0], a_strides[1], _p(x), x_strides[0], x_strides[1],
                      _p(_opt(order, "order", torch.int32)), _p(_opt(seg, "seg", torch.int32)), _p(part), S,
                      G, M, Cn, T, KS, dil, nsplit, _stream()), "bm_gemm_nt")
-    if _on_side_stream is not None:
-        _protect_on_side_stream(a, x, out, order, seg)
-        if mode == "f16x2":
-            _protect_on_side_stream(a_amax, x_amax, a_rows)
     if _timer is not None:
-        suffix = {"f32": "", "bf16": "_bf16", "f32x3": "_x3", "f16x2": "_h2w"}[mode]
+        suffix = {"f32": "", "f32x3": "_x3", "f16x2": "_h2w"}[mode]
         _timer.launch(f"gemm_nt{suffix}_kernel<KS={KS}>", 2.0 * S * T * M * Cn * KS, launch)
     else:
         launch()
@@ -571,104 +553,6 @@ def gemm_nt(a: torch.Tensor, x: torch.Tensor, S: int, M: int, Cn: int, T: int, K
         check(lib().bm_reduce_splits(_p(part), _p(out), G, nsplit, M, Cn, KS, *out_strides,
                                      _stream()), "bm_reduce_splits")
     return out
-
-
-# ------------------------------------------------------------------------------------------------
-# Side stream of the backward pass.  The weight gradient of a conv layer and its data gradient both consume dy and
-# nothing else links them, so the weight-gradient contraction (and its split fold) is enqueued on a second HIP
-# stream: the two MFMA kernels share the chip, their tiles fall out of step, and one kernel's store drains /
-# prologues (19 % / 10 % of a tile with the matrix pipe idle) run under the other's main loops;
-# the chains of small latency-bound launches at both ends of the backward pass overlap with weight gradients too.
-# Ordering: the side stream waits for the current stream when a contraction is handed over (dy and its maxima are
-# complete), the current stream waits for the side stream when the autograd engine finishes the backward pass (engine
-# callback: `loss.backward()` returns with every gradient ordered on the caller's stream, whoever the caller is --
-# Solver, the reference's solver loop, or a test).  BM_WGRAD_STREAM=0: everything on one stream (A/B switch).
-_WGRAD_STREAM = _os.environ.get("BM_WGRAD_STREAM", "1") == "1"
-_WGRAD_STREAM_PRIORITY = int(_os.environ.get("BM_WGRAD_STREAM_PRIORITY", "0"))   # 0 = like the main stream; A/B knob
-_side_streams: tp.Dict[tp.Tuple[int, int, int], tuple] = {}    # (device, stream, thread) -> (that stream, its side stream)
-_side_pending: tp.Dict[tp.Tuple[int, int, int], bool] = {}                 # ... -> a join is owed (callback queued)
-side_stream_launches = 0     # contractions handed to a side stream (tests / bench bookkeeping)
-
-
-def set_wgrad_stream(on: bool):
-    """Switch the weight-gradient side stream on / off at run time (bench.py measures both)."""
-    global _WGRAD_STREAM
-    join_side_streams()
-    _WGRAD_STREAM = bool(on)
-
-
-def _join_side_stream(key):
-    if _side_pending.get(key):
-        cur, side = _side_streams[key]
-        cur.wait_stream(side)
-        _side_pending[key] = False
-
-
-def join_side_streams():
-    """Every stream that handed work to a side stream waits for it (idempotent, no host sync)."""
-    for key in list(_side_pending):
-        _join_side_stream(key)
-
-
-_on_side_stream: tp.Optional[torch.cuda.Stream] = None     # set while a side_stream_of_backward block runs
-
-
-def _protect_on_side_stream(*tensors):
-    """Every tensor a kernel launched on the side stream reads or writes -- the operands, but also the small ones
-    that travel with them (per-row maxima, amax slots, index tables) -- must not be recycled by the caching allocator
-    of the stream that owns it while the side stream still uses it: a 1 280-byte row-maxima buffer freed with its
-    gradient tensor is handed to the next layer's launch within microseconds."""
-    side = _on_side_stream
-    if side is not None:
-        for t in tensors:
-            if t is not None and t.is_cuda:
-                t.record_stream(side)
-
-
-class side_stream_of_backward:
-    """``with side_stream_of_backward(tensors...) as on:`` -- inside a backward function: runs the body on the side
-    stream of the current (device, stream) when the switch is on (``on`` tells), after making it wait for the current
-    stream; the tensors named are protected from re-use by the caching allocator until the side stream is done with
-    them (record_stream); the join is queued on the autograd engine's completion callback once per backward pass."""
-
-    def __init__(self, *tensors):
-        self.tensors = [t for t in tensors if t is not None]
-        self.ctx = None
-
-    def __enter__(self):
-        if not _WGRAD_STREAM or not self.tensors:
-            return False
-        dev = self.tensors[0].device
-        cur = torch.cuda.current_stream(dev)
-        key = (dev.index if dev.index is not None else torch.cuda.current_device(), cur.cuda_stream,
-               _threading.get_ident())
-        if key not in _side_streams:
-            _side_streams[key] = (cur, torch.cuda.Stream(device=dev, priority=_WGRAD_STREAM_PRIORITY))
-        side = _side_streams[key][1]
-        if not _side_pending.get(key):
-            try:
-                # (the engine runs the callback on whichever thread completes the graph task: the closure names the
-                # stream pair, not "the current stream")
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side_stream(key))
-            except RuntimeError:
-                return False            # not inside a backward pass (a direct call of the function): stay on this stream
-            _side_pending[key] = True
-        side.wait_stream(cur)
-        for t in self.tensors:
-            t.record_stream(side)
-        global side_stream_launches, _on_side_stream
-        side_stream_launches += 1
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        _on_side_stream = side
-        return True
-
-    def __exit__(self, *exc):
-        global _on_side_stream
-        if self.ctx is not None:
-            _on_side_stream = None
-            self.ctx.__exit__(*exc)
-        return False
 
 
 class _DirectArmed:
@@ -703,7 +587,7 @@ def grad_destination(param: torch.Tensor) -> tp.Optional[torch.Tensor]:
     takes part in the graph twice gets a fresh tensor the second time, and autograd accumulates as usual.  The
     returned view becomes ``param.grad`` without a copy (``FlatAdam.collect_grads`` recognises the address)."""
     dst = getattr(param, "_bm_grad_dst", None)
-    if dst is None or dst[1][0] or param.grad is not None or not _DIRECT_GRADS or not _direct_armed.on:
+    if dst is None or dst[1][0] or param.grad is not None or not _direct_armed.on:
         return None
     dst[1][0] = True
     return dst[0]
@@ -713,8 +597,7 @@ def gemm_nt_partials(a, x, S, M, Cn, T, a_strides, x_strides, nsplit=None):
     """Split-K partial tiles [nsplit][M][Cn] (KS=1, one group), consumed by clip_ce."""
     _req(a, "gemm_nt.a")
     _req(x, "gemm_nt.x")
-    # scores feed a softmax: exact fp32 or an fp32-accurate path, never plain bf16
-    mode = "f32" if _compute_dtype == "bf16" else _compute_dtype
+    mode = _compute_dtype
     if mode == "f16x2" and not lib().bm_gemm_nt_h2_covers(M, Cn, 1, S, T, 1, 1, 0):
         mode = "f32x3"
     # the score contraction proper (dense [M][T] x [Cn][T]): 256 x 256 tiles, transposed vector stores

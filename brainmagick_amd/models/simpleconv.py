@@ -17,10 +17,9 @@ from .common import (
 from .. import functional as BF
 from .. import hip_ops as H
 
-import os
 
 # A/B switch (measurement / tests): "0" keeps the three front-end layers as three kernels even where they compose
-_FUSE_FRONT_END = os.environ.get("BM_FUSE_FRONT_END", "1") == "1"
+_FUSE_FRONT_END = True      # tests flip it to compare the composed front end with the three-layer chain
 
 
 class SimpleConv(nn.Module):

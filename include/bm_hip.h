@@ -61,19 +61,6 @@ int bm_conv1d_nn(const float* x, long x_bstride, const float* wpacked, const int
                  long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                  int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
 
-/* ---- OPT-IN bf16-operand / fp32-accumulate variant (conv_nn_bf16.hip): v_mfma_f32_32x32x16_bf16 ----
- * Same contract as bm_conv1d_nn; x / bias / residual / outputs stay fp32, the MFMA operands are
- * rounded to bf16 while staged into LDS.  Not the parity-green default (tolerance 1e-2). */
-int bm_conv_bf16_mt_for(int M);
-int bm_conv_bf16_mpad(int M);
-long bm_packed_weight_elems_bf16(int G, int M, int Cin, int KS);
-int bm_pack_weights_bf16(const float* src, void* dst, int G, int M, int Cin, int KS, long sg, long sm,
-                         long sc, long sj, int flip, const float* alpha_ptr, void* stream);
-int bm_conv1d_nn_bf16(const float* x, long x_bstride, const void* wpacked, const int* widx,
-                      const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
-                      long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
-                      int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
-
 /* ---- fp32-ACCURATE contraction on the bf16 matrix cores: exact 3-way bf16 split of both operands,
  * six partial products per MFMA block, fp32 accumulate (conv_nn_x3.hip / gemm_nt_x3.hip).  Same
  * contracts as bm_conv1d_nn / bm_gemm_nt; compute mode "f32x3". */
@@ -84,19 +71,12 @@ int bm_conv1d_nn_x3(const float* x, long x_bstride, const void* wpacked, const i
                     const float* bias, long bias_gstride, const float* ep_scale, const float* ep_shift, const float* res,
                     long res_bstride, float* y_pre, float* y_out, long y_bstride, float* stats, int B,
                     int Cin, int M, int T, int KS, int dil, int act, float leak, void* stream);
-/* 1 when bm_conv1d_nn_x3 takes the wide-tile kernel (conv_nn_x3w.hip: 320 x 192 workgroup tile, one
- * wavefront per SIMD, weight slabs by LDS DMA) for this shape, 0 for conv_nn_x3_kernel.  Used by the
- * host-side kernel timer to label launches the way rocprofv3 names them. */
-int bm_conv_x3_is_wide(int Cin, int M, int T, int KS, int dil, int with_stats);
 int bm_gemm_nt_x3(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
                   long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
                   int Cn, int T, int KS, int dil, int nsplit, void* stream);
-/* split count bm_gemm_nt_x3 wants for this shape (one 320 x 64 x 3-tap workgroup per CU when the wide-tile
- * kernel of gemm_nt_x3w.hip covers it, else bm_gemm_nt_suggest_splits). */
-int bm_gemm_nt_x3_suggest_splits(int M, int Cn, int KS, int S, int T, int G, int dil);
-int bm_gemm_nt_bf16(const float* a, long a_sstride, long a_rstride, const float* x, long x_sstride,
-                    long x_rstride, const int* order, const int* seg, float* part, int S, int G, int M,
-                    int Cn, int T, int KS, int dil, int nsplit, void* stream);
+/* tile height (MFMA row blocks: 3, 4, 5) and padded row count of the narrow f32x3 kernels */
+int bm_conv_x3_mt_for(int M);
+int bm_conv_x3_mpad(int M);
 
 /* ---- fp32-ACCURATE contraction on the f16 matrix cores, compute mode "f16x2" (conv_nn_h2w.hip): every operand
  * is scaled by a power of two (per tensor for activations, per output row for weights) and split into two f16
@@ -122,11 +102,9 @@ int bm_pack_weights_h2_batch(const void* jobs_dev, int njobs, int total_blocks, 
 /* amax slots and workspace: a slot is 8 floats whose maximum is max|x|; `amax_ws` is 16384 floats of scratch that
  * the producers of one stream may share.  bm_amax / bm_amax_checked overwrite the slot (per-workgroup partial maxima
  * in `amax_ws`, folded by a one-workgroup kernel), and so do the PRODUCERS (`amax_out` / `y_amax_out` arguments
- * below) by default.  With BM_AMAX_ATOMIC=1 in the environment (bm_amax_is_atomic() == 1; measured slower, kept as
- * an A/B switch) the producers raise the slot with atomic max instead: the caller then hands them a ZEROED slot
- * (hip_ops carves slots out of zeroed pools in either mode). */
+ * below).  (bm_clip_cand_prep is the one producer that raises its slot with atomic max: it wants it ZEROED; hip_ops
+ * carves every slot out of zeroed pools.) */
 int bm_amax_ws_elems(void);
-int bm_amax_is_atomic(void);
 int bm_amax(const float* x, long n, float* out, float* amax_ws, void* stream);
 /* Same pass, plus the reference's finiteness assert (bm/solver.py:258-260): *nonfinite_flag (device int, nullable)
  * is set to 1 when x holds an inf or a nan. */

@@ -206,12 +206,12 @@ def test_data_parallel_exchange_world2_gloo(tmp_path):
         assert p.returncode == 0 and f"WORKER_OK {r}" in out, out
 
 
-_WIDE = ("gemm_nt_x3w.hip", "conv_nn_x3w.hip", "gemm_nt_h2w.hip", "conv_nn_h2w.hip")
+_WIDE = ("gemm_nt_h2w.hip", "conv_nn_h2w.hip")
 _asm_cache = {}
 
 
 def _wide_kernel_asm():
-    """gfx950 assembly of the wide-tile kernels (compiled once per session, the four files in parallel)."""
+    """gfx950 assembly of the wide-tile kernels (compiled once per session, the two files in parallel)."""
     import concurrent.futures
     import shutil
     import subprocess
@@ -248,7 +248,7 @@ def test_wide_kernels_do_not_spill():
 
 
 def test_hand_issued_loads_are_not_touched_before_their_wait():
-    """conv_nn_h2w / conv_nn_x3w issue the input-window loads through inline asm with hand-counted waits (a
+    """conv_nn_h2w issues the input-window loads through inline asm with hand-counted waits (a
     compiler-visible load next to the LDS-DMA weight copies would drain the DMA queue at every use).  hipcc may
     copy or re-use an asm load's destination register while the load is still in flight; scripts/audit_asm_loads.py
     checks on the generated ISA that it does not.  (gemm_nt_h2w uses compiler-visible loads for exactly that
@@ -258,7 +258,7 @@ def test_hand_issued_loads_are_not_touched_before_their_wait():
     audit = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(audit)
     asm = _wide_kernel_asm()
-    for name in ("conv_nn_h2w.hip", "conv_nn_x3w.hip"):
+    for name in ("conv_nn_h2w.hip",):
         violations = audit.audit_text(asm[name])
         assert not violations, (name, violations[:5])
     assert "buffer_load" not in "".join(l for l in asm["gemm_nt_h2w.hip"].splitlines() if "ASMSTART" in l)

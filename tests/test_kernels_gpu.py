@@ -38,7 +38,7 @@ CONV_CASES = [
     (33, 40, 5, 8, 100, 2),
     (16, 16, 3, 4, 7, 1),      # T smaller than the dilation halo
     (5, 1024, 1, 1, 130, 1),
-    # shapes the wide-tile f32x3 kernels cover (conv_nn_x3w / gemm_nt_x3w: M % 320 == 0, Cin % 64 == 0)
+    # shapes of the wide 320-row tiles (M % 320 == 0, Cin % 64 == 0)
     (320, 320, 3, 2, 360, 4),
     (64, 640, 3, 16, 343, 3),
     (128, 320, 3, 1, 361, 3),
@@ -285,7 +285,7 @@ def test_clip_loss_at_the_whole_node_shape(H):
     g = _gen(77)
     est = (torch.randn(B, Fd, T, generator=g) * 0.5).requires_grad_(True)
     cand = torch.randn(Bc, Fd, T, generator=g)
-    est.data += 0.4 * cand[off:off + B]                       # planted: a non-trivial softmax
+    est.data += 0.02 * cand[off:off + B]                      # planted: target scores ~4 above the rest, far from saturation
     valid = torch.ones(Bc)
     masked = [3, 300, 301, 1500, 1791]        # (none inside the target block 1792 .. 2047)
     valid[masked] = 0
@@ -494,40 +494,6 @@ def test_retrieval_rules_against_reference_fixture(H):
                             n_negatives=meta["n_negatives"], topx=meta["topx"], generator=gen, batch_size=16)
     assert got["wer"] == pytest.approx(float(g.raw["wer/wer"]), abs=1e-9)
     assert got["wer_vocab"] == pytest.approx(float(g.raw["wer/wer_vocab"]), abs=1e-9)
-
-
-@pytest.mark.gpu
-def test_wide_and_narrow_f32x3_kernels_agree(tmp_path):
-    """The wide-tile kernels (conv_nn_x3w / gemm_nt_x3w) and the 160x128 / 64x64 ones they replace for the
-    big layers are two implementations of the same fp32-accurate contraction: run the same conv forward,
-    data gradient and weight gradient with BM_X3_WIDE=0 in a second process and compare."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / "narrow.py"
-    script.write_text(
-        "import sys, torch\n"
-        f"sys.path.insert(0, {str(Path(__file__).resolve().parent.parent)!r})\n"
-        "import brainmagick_amd\n"
-        "from brainmagick_amd import hip_ops as H\n"
-        "brainmagick_amd.set_compute_dtype('f32x3')\n"
-        "g = torch.Generator().manual_seed(3)\n"
-        "B, Cin, M, KS, dil, T = 5, 320, 640, 3, 4, 361\n"
-        "x = torch.randn(B, Cin, T, generator=g).cuda(); w = (torch.randn(M, Cin, KS, generator=g) / 31).cuda()\n"
-        "dy = torch.randn(B, M, T, generator=g).cuda()\n"
-        "y = H.conv_nn(x, H.pack_conv_fwd(w), M, KS, dil)[1]\n"
-        "dx = H.conv_nn(dy, H.pack_conv_dgrad(w), Cin, KS, dil)[1]\n"
-        "dw = H.gemm_nt(dy, x, B, M, Cin, T, KS, dil)\n"
-        "wide = H.lib().bm_conv_x3_is_wide(Cin, M, T, KS, dil, 0)\n"
-        "torch.save({'y': y.cpu(), 'dx': dx.cpu(), 'dw': dw.cpu(), 'wide': wide}, sys.argv[1])\n")
-    outs = {}
-    for tag, env in (("wide", {}), ("narrow", {"BM_X3_WIDE": "0"})):
-        out = tmp_path / f"{tag}.pt"
-        subprocess.run([sys.executable, str(script), str(out)], check=True, env={**os.environ, **env})
-        outs[tag] = torch.load(out)
-    assert outs["wide"]["wide"] == 1 and outs["narrow"]["wide"] == 0
-    for k in ("y", "dx", "dw"):
-        assert rel_l2(outs["wide"][k], outs["narrow"][k].double()) < 2e-6, k
 
 
 def test_scores_contraction_with_an_operand_over_2gb(H):
