@@ -213,6 +213,9 @@ extern "C" int bm_affine_act_res(const float* y, const float* scale, const float
 // Pass 1 (bn_bwd_reduce): per-(channel, split) partial sums.  Pass 2 (bn_bwd_apply): dy + sum(dy).
 // ------------------------------------------------------------------------------------------------
 #define NSPLIT_MAX 32
+#ifndef BWD_UNROLL
+#define BWD_UNROLL 4      // slab positions per loop trip of the backward kernels (see bn_bwd_reduce_kernel)
+#endif
 
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
@@ -228,15 +231,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     double acc[2] = {0, 0};
     float s0 = 0.f, s1 = 0.f;
     const int nb = b1 - b0;
-    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
-        const int bl = w.bl, tv = w.tv;
-        const long off = ((long)(b0 + bl) * C + c) * T + (long)tv * VEC;
-        const Pack<VEC> d = Pack<VEC>::ld(dout + off), v = Pack<VEC>::ld(y + off);
+    // BWD_UNROLL positions per trip, all loads issued before the first use: two 16-byte loads in flight per thread
+    // left these (channel, split) kernels latency-bound at ~5.0 TB/s (the flat-grid forward kernels reach 5.8-6.0)
+    SlabWalk w(TV, threadIdx.x, blockDim.x);
+    while (w.bl < nb) {
+        long off[BWD_UNROLL];
+        bool ok[BWD_UNROLL];
+        Pack<VEC> d[BWD_UNROLL], v[BWD_UNROLL];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float dz = d.v[i] * bm_act_grad(v.v[i] * sc + shf, act, leak);
-            s0 += dz;
-            s1 += dz * ((v.v[i] - mu) * is);
+        for (int u = 0; u < BWD_UNROLL; ++u) {
+            // (unconditional loads -- a position past the slab re-reads the trip's first one -- so that nothing but
+            // the address arithmetic sits between the 2 * BWD_UNROLL loads)
+            ok[u] = w.bl < nb;
+            off[u] = ok[u] ? ((long)(b0 + w.bl) * C + c) * T + (long)w.tv * VEC : off[0];
+            d[u] = Pack<VEC>::ld(dout + off[u]);
+            v[u] = Pack<VEC>::ld(y + off[u]);
+            if (ok[u]) w.next();
+        }
+#pragma unroll
+        for (int u = 0; u < BWD_UNROLL; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float dz = d[u].v[i] * bm_act_grad(v[u].v[i] * sc + shf, act, leak);
+                s0 += dz;
+                s1 += dz * ((v[u].v[i] - mu) * is);
+            }
         }
     }
     acc[0] = s0; acc[1] = s1;
@@ -283,22 +303,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
     float sdy = 0.f;
     const int nb = b1 - b0;
-    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
-        const int bl = w.bl, tv = w.tv;
-        const long off = ((long)(b0 + bl) * C + c) * T + (long)tv * VEC;
-        const Pack<VEC> d = Pack<VEC>::ld(dout + off), v = Pack<VEC>::ld(y + off);
-        Pack<VEC> o;
+    SlabWalk w(TV, threadIdx.x, blockDim.x);
+    while (w.bl < nb) {
+        long off[BWD_UNROLL];
+        bool ok[BWD_UNROLL];
+        Pack<VEC> d[BWD_UNROLL], v[BWD_UNROLL];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float dz = d.v[i] * bm_act_grad(v.v[i] * sc + shf, act, leak);
-            float g = dz;
-            if (bn_train) g = sc * (dz - k1 - ((v.v[i] - mu) * is) * k2);
-            else if (scale) g = sc * dz;
-            o.v[i] = g;
-            sdy += g;
-            amx = fmaxf(amx, fabsf(g));
+        for (int u = 0; u < BWD_UNROLL; ++u) {
+            // (unconditional loads -- a position past the slab re-reads the trip's first one -- so that nothing but
+            // the address arithmetic sits between the 2 * BWD_UNROLL loads)
+            ok[u] = w.bl < nb;
+            off[u] = ok[u] ? ((long)(b0 + w.bl) * C + c) * T + (long)w.tv * VEC : off[0];
+            d[u] = Pack<VEC>::ld(dout + off[u]);
+            v[u] = Pack<VEC>::ld(y + off[u]);
+            if (ok[u]) w.next();
         }
-        o.st(dy + off);
+#pragma unroll
+        for (int u = 0; u < BWD_UNROLL; ++u) {
+            if (!ok[u]) continue;
+            Pack<VEC> o;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float dz = d[u].v[i] * bm_act_grad(v[u].v[i] * sc + shf, act, leak);
+                float g = dz;
+                if (bn_train) g = sc * (dz - k1 - ((v[u].v[i] - mu) * is) * k2);
+                else if (scale) g = sc * dz;
+                o.v[i] = g;
+                sdy += g;
+                amx = fmaxf(amx, fabsf(g));
+            }
+            o.st(dy + off[u]);
+        }
     }
     bm_publish_amax(amx, amax_ws, amax_sh);
     double acc[1] = {(double)sdy};
@@ -558,26 +593,40 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
     const int TV = T / VEC;
     float sa = 0.f, sg = 0.f;
     const int nb = b1 - b0;
-    for (SlabWalk w(TV, threadIdx.x, blockDim.x); w.bl < nb; w.next()) {
-        const int bl = w.bl, tv = w.tv;
-        const int b = b0 + bl;
-        const long offo = ((long)b * H + hch) * T + (long)tv * VEC;
-        const long offa = ((long)b * 2 * H + hch) * T + (long)tv * VEC;
-        const long offg = offa + (long)H * T;
-        const Pack<VEC> d = Pack<VEC>::ld(dout + offo), a = Pack<VEC>::ld(u + offa), g = Pack<VEC>::ld(u + offg);
-        Pack<VEC> oa, og;
+    SlabWalk w(TV, threadIdx.x, blockDim.x);
+    while (w.bl < nb) {
+        long offa[BWD_UNROLL];
+        bool ok[BWD_UNROLL];
+        Pack<VEC> d[BWD_UNROLL], a[BWD_UNROLL], g[BWD_UNROLL];
+        long offo[BWD_UNROLL];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float sgm = 1.f / (1.f + expf(-g.v[i]));
-            oa.v[i] = d.v[i] * sgm;
-            og.v[i] = d.v[i] * a.v[i] * sgm * (1.f - sgm);
-            sa += oa.v[i];
-            sg += og.v[i];
-            amx = fmaxf(amx, fabsf(oa.v[i]));
-            amx_g = fmaxf(amx_g, fabsf(og.v[i]));
+        for (int q = 0; q < BWD_UNROLL; ++q) {
+            ok[q] = w.bl < nb;
+            const int b = b0 + w.bl;
+            offa[q] = ok[q] ? ((long)b * 2 * H + hch) * T + (long)w.tv * VEC : offa[0];
+            offo[q] = ok[q] ? ((long)b * H + hch) * T + (long)w.tv * VEC : offo[0];
+            d[q] = Pack<VEC>::ld(dout + offo[q]);
+            a[q] = Pack<VEC>::ld(u + offa[q]);
+            g[q] = Pack<VEC>::ld(u + offa[q] + (long)H * T);
+            if (ok[q]) w.next();
         }
-        oa.st(du + offa);
-        og.st(du + offg);
+#pragma unroll
+        for (int q = 0; q < BWD_UNROLL; ++q) {
+            if (!ok[q]) continue;
+            Pack<VEC> oa, og;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float sgm = 1.f / (1.f + expf(-g[q].v[i]));
+                oa.v[i] = d[q].v[i] * sgm;
+                og.v[i] = d[q].v[i] * a[q].v[i] * sgm * (1.f - sgm);
+                sa += oa.v[i];
+                sg += og.v[i];
+                amx = fmaxf(amx, fabsf(oa.v[i]));
+                amx_g = fmaxf(amx_g, fabsf(og.v[i]));
+            }
+            oa.st(du + offa[q]);
+            og.st(du + offa[q] + (long)H * T);
+        }
     }
     if (amax_ws.ws) {
         // two-stage mode: one partial per ROW of du, laid out [nsplit][2 H] (per-channel maxima, see bm_glu_bwd)
