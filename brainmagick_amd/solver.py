@@ -29,6 +29,8 @@ class Solver:
                  n_negatives: tp.Optional[int] = None, negative_pool_size: tp.Optional[int] = None):
         assert negatives in ("local", "node")
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None and torch.cuda.is_available():
+            self.device = torch.device("cuda", torch.cuda.current_device())      # comparable with tensor.device
         self.model = model.to(self.device)
         self.loss = (loss or ClipLoss()).to(self.device)
         self.feature_model = feature_model.to(self.device) if feature_model is not None else None

@@ -433,6 +433,15 @@ def test_loopback_communicator_runs_the_data_parallel_exchange_in_process():
     assert distrib.comm() is None and not distrib.is_distributed()
 
 
+def test_shutdown_forgets_the_rendezvous_store():
+    """a second init() in the same process (another MASTER_PORT / WORLD_SIZE) must not reuse the first
+    rendezvous store."""
+    from brainmagick_amd import distrib
+    distrib._store_cache = object()
+    distrib.shutdown()
+    assert distrib._store_cache is None and distrib.comm() is None
+
+
 def test_bench_self_launch_command():
     """`python bench.py --gpus N` outside torchrun re-launches itself as the driver would launch it."""
     import importlib.util

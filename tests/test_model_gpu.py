@@ -304,6 +304,34 @@ def test_out_of_range_subject_index_raises_like_the_reference_gather():
     solver.train_step(sb)                              # flag was cleared
 
 
+def test_deferred_asserts_of_the_last_step_are_not_lost():
+    """the ClipLoss mask assert (bm/losses.py:110) and the index check of a step ride on the device-side
+    flag word that the NEXT step reads -- the last step of a run has no next one: `check_pending_flags()` (also called
+    by eval_step / predict / state_dict) reports it, and raising one condition leaves the other pending."""
+    from brainmagick_amd import hip_ops as H
+    from brainmagick_amd.solver import Solver
+    model, cfg = _small_model()
+    sb = synthetic.make_batch(4, 20, 32, 10, 3, seed=5)
+    solver = Solver(model)
+    solver.train_step(sb)
+    solver.check_pending_flags()                        # clean
+    holes = sb.replace(features_mask=sb.features_mask.clone())
+    holes.features_mask[1, 0, 3] = False
+    solver.train_step(holes)                            # the optimizer step is taken; the verdict is on the device
+    with pytest.raises(AssertionError, match="mask"):
+        solver.check_pending_flags()
+    solver.check_pending_flags()                        # reported once
+    with pytest.raises(AssertionError, match="mask"):
+        solver.eval_step(holes)                         # an evaluation loop reads its own step
+    # an index error raised through hip_ops leaves a pending mask verdict alone
+    bad = holes.replace(subject_index=torch.tensor([0, 1, 7, 2]))
+    solver.train_step(bad)
+    with pytest.raises(IndexError):
+        H.raise_if_index_error("cuda")
+    with pytest.raises(AssertionError, match="mask"):
+        solver.check_pending_flags()
+
+
 def test_node_negatives_accept_per_rank_rejection_with_constant_candidates():
     """Whole-node negatives next to a ScaleReject that can reject (round 4: equal blocks of the nominal batch size,
     padding rows masked -- test_replicas_with_per_rank_rejection_and_whole_node_negatives); still refused with a
