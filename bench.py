@@ -535,6 +535,17 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     solver = Solver(model, device=str(dev), negatives=negatives)
     stream = BatchStream(args.workload, B, rank, dev)
+    zero_operands = bool(os.environ.get("BM_BENCH_ZERO_OPERANDS"))
+    if zero_operands:
+        # DVFS probe (never a result): the same launches, addresses and memory traffic on operands that do not toggle
+        # -- all parameters and inputs zero -- show what the power manager takes from the matrix kernels on real data
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.zero_()
+        hip_ops.weights_changed()
+        for sb in stream.batches:
+            sb.meg.zero_()
+            sb.features.zero_()
 
     def timed_steps(k):
         # (a full Python garbage collection costs this process ~70 ms once, 30-40 steps in: keep it out of whichever
@@ -611,7 +622,8 @@ def main():
     total_kernel_ms = sum(v["avg_ms"] * v["launches"] for v in ksum.values()) / args.steps
     step_bytes = algorithmic_bytes_per_step(c["C"], c["T"], c["F"], B, n_params)
     out = {
-        "metric": "segments/s, 208-ch x 360-sample SimpleConv + ClipLoss training step",
+        "metric": ("segments/s, 208-ch x 360-sample SimpleConv + ClipLoss training step" if not zero_operands else
+                   "DVFS PROBE ON ALL-ZERO OPERANDS -- not a result"),
         "value": world * B * args.steps / elapsed,
         "unit": "segments/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -79,10 +79,31 @@ class _GLU(nn.Module):
     """Marker for nn.GLU(dim=1) (fused in GLUConvFn)."""
 
 
+class LayerScale(nn.Module):
+    """bm/models/common.py:65-76 (Touvron et al. 2021): a learnt per-channel factor on the residual branch,
+    ``boost * scale``, initialised to ``init``.  Off the hot path (no grid of the paper sets it): a broadcast
+    multiplication on the GPU, autograd included."""
+    def __init__(self, channels: int, init: float = 0.1, boost: float = 5.):
+        super().__init__()
+        self.scale = nn.Parameter(torch.zeros(channels, requires_grad=True))
+        self.scale.data[:] = init / boost
+        self.boost = boost
+
+    def forward(self, x):
+        return (self.boost * self.scale[:, None]) * x
+
+
 class ConvSequence(nn.Module):
     """bm/models/common.py:79-151.  Same constructor; builds the same ``sequence`` / ``glus``
     module lists (so ``sequence.k.0`` is the conv, ``sequence.k.1`` the BatchNorm1d, ``glus.k.0``
-    the GLU conv) but runs each layer as fused HIP kernels."""
+    the GLU conv -- and, with the options no grid of the paper uses, the Dropout / rewrite conv / LayerScale /
+    post-skip modules at the reference's indices) but runs each layer as fused HIP kernels.
+
+    The hot path is conv [-> BatchNorm] -> activation [-> + input] as ONE fused function.  ``dropout`` /
+    ``dropout_input`` (nn.Dropout), ``rewrite`` (1x1 conv + LeakyReLU), ``scale`` (LayerScale) and ``post_skip``
+    (a depthwise 1x1 conv without bias = one factor per channel) sit between the activation and the skip
+    addition: a layer that has any of them runs the fused function without its residual, the extras as (GPU) torch
+    ops or the 1x1 HIP conv, and the addition as one streaming launch -- slower than the hot path, never an error."""
 
     def __init__(self, channels: tp.Sequence[int], kernel: int = 4, dilation_growth: int = 1,
                  dilation_period: tp.Optional[int] = None, stride: int = 2,
@@ -92,9 +113,7 @@ class ConvSequence(nn.Module):
                  activation_on_last: bool = True, post_skip: bool = False, glu: int = 0,
                  glu_context: int = 0, glu_glu: bool = True, activation: tp.Any = None) -> None:
         super().__init__()
-        unsupported = dict(stride=stride != 1, dropout=bool(dropout), groups=groups != 1,
-                           decode=decode, dropout_input=bool(dropout_input),
-                           scale=scale is not None, rewrite=rewrite, post_skip=post_skip)
+        unsupported = dict(stride=stride != 1, groups=groups != 1, decode=decode)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(
@@ -113,19 +132,38 @@ class ConvSequence(nn.Module):
         for k, (chin, chout) in enumerate(zip(channels[:-1], channels[1:])):
             layers: tp.List[nn.Module] = []
             is_last = k == len(channels) - 2
+            plan = dict(dilation=1, act=None, bn=None, glu=None, pre=None, post=[])
+            if k == 0 and dropout_input:
+                assert 0 < dropout_input < 1
+                layers.append(nn.Dropout(dropout_input))
+                plan["pre"] = layers[-1]
             if dilation_period and (k % dilation_period) == 0:
                 dilation = 1
             pad = kernel // 2 * dilation
             layers.append(nn.Conv1d(chin, chout, kernel, 1, pad, dilation=dilation))
-            plan = dict(dilation=dilation, act=None, bn=False, glu=None)
+            plan["conv"] = layers[-1]
+            plan["dilation"] = dilation
             dilation *= dilation_growth
             if activation_on_last or not is_last:
                 if batch_norm:
                     layers.append(nn.BatchNorm1d(num_features=chout))
-                    plan["bn"] = True
+                    plan["bn"] = layers[-1]
                 act = activation()
                 layers.append(act)
                 plan["act"] = act
+                if dropout:
+                    layers.append(nn.Dropout(dropout))
+                    plan["post"].append(("dropout", layers[-1]))
+                if rewrite:
+                    layers += [nn.Conv1d(chout, chout, 1), _Activation("leaky", leakiness)]
+                    plan["post"].append(("rewrite", layers[-2], layers[-1]))
+            if chin == chout and skip:
+                if scale is not None:
+                    layers.append(LayerScale(chout, scale))
+                    plan["post"].append(("scale", layers[-1]))
+                if post_skip:
+                    layers.append(nn.Conv1d(chout, chout, 1, groups=chout, bias=False))
+                    plan["post"].append(("post_skip", layers[-1]))
             self.sequence.append(nn.Sequential(*layers))
             if glu and (k + 1) % glu == 0:
                 ch = 2 * chout if glu_glu else chout
@@ -141,20 +179,34 @@ class ConvSequence(nn.Module):
     def forward(self, x: tp.Any) -> tp.Any:
         for module_idx, module in enumerate(self.sequence):
             plan = self._plan[module_idx]
-            conv = module[0]
+            conv = plan["conv"]
             act = plan["act"]
             code = act.code if act is not None else H.ACT_NONE
             leak = act.leak if act is not None else 0.
             residual = self.skip and conv.in_channels == conv.out_channels
-            if plan["bn"]:
-                bn = module[1]
+            old_x = x
+            if plan["pre"] is not None:
+                x = plan["pre"](x)                                  # nn.Dropout on the input of the sequence
+            fused_residual = residual and not plan["post"] and plan["pre"] is None
+            if plan["bn"] is not None:
+                bn = plan["bn"]
                 x = BF.ConvBNActFn.apply(
                     x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                    bn.num_batches_tracked, self.training, plan["dilation"], code, leak, residual,
+                    bn.num_batches_tracked, self.training, plan["dilation"], code, leak, fused_residual,
                     bn.momentum, bn.eps)
             else:
-                y = BF.Conv1dFn.apply(x, conv.weight, conv.bias, plan["dilation"], code, leak, False)
-                x = _AddFn.apply(y, x) if residual else y
+                x = BF.Conv1dFn.apply(x, conv.weight, conv.bias, plan["dilation"], code, leak, False)
+            for op in plan["post"]:                                 # the off-path extras, in the reference's order
+                if op[0] == "dropout":
+                    x = op[1](x)
+                elif op[0] == "rewrite":
+                    x = BF.Conv1dFn.apply(x, op[1].weight, op[1].bias, 1, op[2].code, op[2].leak, False)
+                elif op[0] == "scale":
+                    x = op[1](x)
+                else:                                               # depthwise 1x1 without bias: one factor per channel
+                    x = x * op[1].weight.view(1, -1, 1)
+            if residual and not (fused_residual and plan["bn"] is not None):
+                x = _AddFn.apply(x if x.is_contiguous() else x.contiguous(), old_x)
             glu = self.glus[module_idx]
             if glu is not None:
                 gconv = glu[0]
@@ -296,6 +348,47 @@ class FourierEmb(nn.Module):
         return H.fourier_emb(positions.contiguous(), self.dimension, self.margin)
 
 
+class ChannelDropout(nn.Module):
+    """bm/models/common.py:273-310 (`simpleconv.dropout`): sensors without a position are zeroed; in training the
+    sensors within ``dropout`` of a random centre are dropped and, with ``rescale``, every sensor is divided by its
+    probability of being kept (estimated from 100 more random centres, like the reference).  Off the hot path (no
+    grid of the paper sets it): GPU torch ops on the de-duplicated layouts."""
+
+    N_TESTS = 100
+
+    def __init__(self, dropout: float = 0.1, rescale: bool = True):
+        super().__init__()
+        self.dropout = dropout
+        self.rescale = rescale
+        self.position_getter = PositionGetter()
+        self.ban_center_override: tp.Optional[torch.Tensor] = None     # test hook: every draw returns this centre
+
+    def _centers(self, n: int, device) -> torch.Tensor:
+        if self.ban_center_override is not None:
+            return self.ban_center_override.to(device, torch.float32).view(1, 2).expand(n, 2)
+        return torch.rand(n, 2, device=device)
+
+    def forward(self, meg, batch):
+        if not self.dropout:
+            return meg
+        B, C, T = meg.shape
+        positions_u, layout_index = self.position_getter.get_unique_layouts(batch, C, meg.device)
+        valid_u = (~self.position_getter.is_invalid(positions_u)).float()                 # [U, C]
+        factor_u = valid_u
+        if self.training:
+            kept = ((positions_u - self._centers(1, meg.device)[0]).norm(dim=-1) > self.dropout).float()
+            factor_u = factor_u * kept
+            if self.rescale:
+                centers = self._centers(self.N_TESTS, meg.device)                         # [N, 2]
+                dist = (positions_u[None] - centers[:, None, None, :]).norm(dim=-1)       # [N, U, C]
+                # (the reference accumulates kept / n_tests in a loop: the same sum in the same order)
+                proba_kept = torch.zeros_like(valid_u)
+                for n in range(self.N_TESTS):
+                    proba_kept += (dist[n] > self.dropout).float() / self.N_TESTS
+                factor_u = factor_u / (1e-8 + proba_kept)
+        return meg * factor_u[layout_index][:, :, None]
+
+
 class ChannelMerger(nn.Module):
     """bm/models/common.py:312-362; parameter ``heads`` [chout, pos_dim]."""
     def __init__(self, chout: int, pos_dim: int = 256,
@@ -303,9 +396,9 @@ class ChannelMerger(nn.Module):
                  n_subjects: int = 200, per_subject: bool = False):
         super().__init__()
         assert pos_dim % 4 == 0
-        if per_subject or usage_penalty > 0.:
-            raise NotImplementedError("merger_per_subject / merger_penalty are outside the MI355X "
-                                      "hot path (unused by the paper's grids, SURVEY.md §2.2)")
+        if per_subject:
+            raise NotImplementedError("merger_per_subject is outside the MI355X hot path (unused by the paper's "
+                                      "grids, SURVEY.md §2.2)")
         self.position_getter = PositionGetter()
         self.per_subject = per_subject
         self.heads = nn.Parameter(torch.randn(chout, pos_dim, requires_grad=True))
@@ -328,6 +421,11 @@ class ChannelMerger(nn.Module):
         B, C, T = meg.shape
         positions_u, layout_index = self.position_getter.get_unique_layouts(batch, C, meg.device)
         ban_center, radius = None, 0.
+        if self.training and self.usage_penalty > 0.:
+            # bm/models/common.py:359-361: usage = weights.mean(dim=(0, 1)).sum() -- every (segment, output channel)
+            # row of the softmax sums to 1, so the mean over rows sums to 1 over the sensors: the penalty is the
+            # CONSTANT usage_penalty (its gradient is round-off noise in the reference, exactly zero here)
+            self._penalty = torch.tensor(float(self.usage_penalty))
         if self.training and self.dropout:
             if self.ban_center_override is not None:
                 ban_center = self.ban_center_override.to(meg.device, torch.float32)

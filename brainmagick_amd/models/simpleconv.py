@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .common import (
-    ConvSequence, ScaledEmbedding, SubjectLayers, ChannelMerger, make_activation)
+    ConvSequence, ScaledEmbedding, SubjectLayers, ChannelMerger, ChannelDropout, make_activation)
 from .. import functional as BF
 from .. import hip_ops as H
 
@@ -49,11 +49,11 @@ class SimpleConv(nn.Module):
                              f"({set(in_channels.keys())} and {set(hidden.keys())})")
         rejected = [name for name, used in dict(
             concatenate=concatenate, dual_path=bool(dual_path), n_fft=n_fft is not None,
-            dropout=dropout > 0., multi_input=set(in_channels) != {"meg"}).items() if used]
+            multi_input=set(in_channels) != {"meg"}).items() if used]
         if rejected:
             raise NotImplementedError(
                 f"SimpleConv options {rejected} are outside the MI355X hot path (STFT / DualPathRNN / "
-                "ChannelDropout / multi-input are unused by the paper's grids, SURVEY.md §2.2)")
+                "multi-input are unused by the paper's grids, SURVEY.md §2.2)")
         if kernel_size % 2 != 1:
             raise AssertionError("For padding to work, this must be verified")       # reference message
         if linear_out and complex_out:
@@ -62,6 +62,7 @@ class SimpleConv(nn.Module):
         activation = make_activation(gelu, relu_leakiness)
 
         width = in_channels["meg"]
+        self.dropout = ChannelDropout(dropout, dropout_rescale) if dropout > 0. else None   # simpleconv.py:103-104
         self.subsampled_meg_channels: tp.Optional[list] = None
         if subsample_meg_channels:
             self._subsample(width, subsample_meg_channels)
@@ -147,6 +148,8 @@ class SimpleConv(nn.Module):
 
         if self.subsampled_meg_channels is not None:
             x = x * self._channel_keep                       # constant 0/1 mask, simpleconv.py:202-205
+        if self.dropout is not None:
+            x = self.dropout(x, batch)                       # simpleconv.py:207-208
         fused = self._front_end_is_linear_chain() and _FUSE_FRONT_END
         if fused:
             positions_u, layout_index, ban_center, radius = self.merger.layouts_and_ban(x, batch)

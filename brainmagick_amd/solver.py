@@ -282,8 +282,11 @@ class Solver:
         loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid)
         if next_batch is not None:
             self.prefetch(next_batch)       # the next step's candidate all-gather runs next to this backward
-        # bm/solver.py:375-380: `training_penalty` of ChannelMerger is identically 0 on this path
-        # (merger_penalty > 0 is rejected at construction) and optim.svd defaults to 0.
+        # bm/solver.py:375-380: `training_penalty` of every module that has one (ChannelMerger with merger_penalty:
+        # a constant, see models/common.py); optim.svd defaults to 0 and stays with the reference
+        for mod in self.model.modules():
+            if hasattr(mod, "training_penalty"):
+                loss = loss + mod.training_penalty.to(loss.device)
         self.optimizer.zero_grad(set_to_none=True)
         with self.optimizer.writing_grads():       # the weight-gradient kernels write straight into the flat bucket
             loss.backward()

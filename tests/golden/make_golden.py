@@ -64,7 +64,20 @@ VARIANTS = {
     "subsample_channels": dict(cfg=variant(subsample_meg_channels=9), training=True, n_steps=1),
     # more candidates than estimates (negatives appended, bm/solver.py:359-371)
     "extra_negatives": dict(cfg=BASE, training=True, n_steps=1, extra_negatives=7),
+    # options outside the paper's grids (round 4: implemented off the hot path instead of rejected): LayerScale,
+    # rewrite conv, post-skip depthwise conv, the (constant) merger usage penalty -- train mode, one step
+    "layer_scale_rewrite_post_skip": dict(cfg=variant(depth=4, scale=0.5, rewrite=True, post_skip=True,
+                                                      relu_leakiness=0.1, merger_penalty=0.3),
+                                          training=True, n_steps=1, n_layouts=2),
+    # ChannelDropout with every random centre pinned to the injected one (fake_rand), rescaled
+    "channel_dropout_train": dict(cfg=variant(depth=4, dropout=0.35, dropout_rescale=True), training=True, n_steps=1,
+                                  n_layouts=2, pad_layout=True),
+    # the Dropout modules shift the sequence indices (state_dict keys); eval mode: identity
+    "conv_dropouts_eval": dict(cfg=variant(depth=4, conv_dropout=0.2, dropout_input=0.1, dropout=0.3),
+                               training=False, n_steps=0, n_layouts=2, pad_layout=True),
 }
+# fixtures the CPU oracle (oracle/bm_oracle.py restates the hot path only) does not cover: HIP path vs reference directly
+OFF_PATH = ("layer_scale_rewrite_post_skip", "channel_dropout_train", "conv_dropouts_eval")
 HIDDEN = 16
 
 
@@ -163,6 +176,8 @@ def run_variant(name, spec, sc, common, losses):
     finally:
         common.torch.rand = real_rand
     out["out/losses"] = np.asarray(losses_seen, dtype=np.float64)
+    if name in OFF_PATH and getattr(model, "merger", None) is not None:
+        out["out/training_penalty"] = np.asarray(float(model.merger.training_penalty))
     for k, v in model.state_dict().items():
         out[f"sd1/{k}"] = v.detach().clone().numpy()
     return out

@@ -11,6 +11,11 @@ MODEL_FIXTURES = ["clip_conv_train", "clip_conv_eval", "no_merger_relu_noskip",
                   "initial_depth2_hidden_subject", "subsample_channels", "extra_negatives"]
 
 
+# options outside the paper's grids, implemented off the hot path (GPU torch ops + the 1x1 HIP conv): the HIP model is
+# held to the live reference directly (the CPU oracle restates the hot path only)
+OFF_PATH_FIXTURES = ["layer_scale_rewrite_post_skip", "channel_dropout_train", "conv_dropouts_eval"]
+
+
 class Golden:
     def __init__(self, name):
         self.name = name

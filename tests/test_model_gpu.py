@@ -7,7 +7,7 @@ import copy
 import pytest
 import torch
 
-from helpers import Golden, MODEL_FIXTURES, rel_l2
+from helpers import Golden, MODEL_FIXTURES, OFF_PATH_FIXTURES, rel_l2
 from oracle import bm_oracle as O
 from brainmagick_amd import synthetic
 
@@ -99,7 +99,7 @@ def _build(meta, sd0):
     return model.cuda()
 
 
-@pytest.mark.parametrize("name", MODEL_FIXTURES)
+@pytest.mark.parametrize("name", MODEL_FIXTURES + OFF_PATH_FIXTURES)
 def test_against_reference_golden(name):
     from brainmagick_amd.losses import ClipLoss
     from brainmagick_amd.optim import FlatAdam
@@ -113,6 +113,8 @@ def test_against_reference_golden(name):
     mask = torch.ones(len(inp["meg"]), 1, meta["T"], dtype=torch.bool, device="cuda")
     if model.merger is not None:
         model.merger.ban_center_override = inp["ban_center"]
+    if getattr(model, "dropout", None) is not None:
+        model.dropout.ban_center_override = inp["ban_center"]       # the fixture pinned every random centre to it
     ref_losses = g.raw["out/losses"]
     if meta["training"] and meta["n_steps"]:
         model.train()
@@ -133,6 +135,8 @@ def test_against_reference_golden(name):
                     assert close(params[k].grad, grads_ref[k], GRAD_TOL, gscale), \
                         (k, rel_l2(params[k].grad, grads_ref[k]))
             assert abs(float(loss) - ref_losses[step]) < LOSS_TOL
+            if "out/training_penalty" in g.raw and model.merger is not None:
+                assert abs(float(model.merger.training_penalty) - float(g.raw["out/training_penalty"])) < 1e-6
             optim.step()
         sd1 = g.group("sd1")
         for k, v in model.state_dict().items():
