@@ -3,8 +3,10 @@ constructor signature (bm/models/simpleconv.py:23-77), module names and ``state_
 that ``bm/train.py:84-86`` can build it unchanged and reference checkpoints load into it; the
 forward pass is a sequence of libbmhip kernels (see ``brainmagick_amd.functional``).
 
-Options the paper's grids never use and that are outside the MI355X hot path raise
-``NotImplementedError`` at construction time (listed in DESIGN.md).
+Options the paper's grids never use are either implemented off the hot path (GPU torch ops around the fused layer
+functions: ``dropout``, ``conv_dropout``, ``dropout_input``, ``scale``, ``rewrite``, ``post_skip``, ``merger_penalty``) or
+raise ``NotImplementedError`` at construction time (``n_fft``, ``dual_path``, ``concatenate``, ``groups``,
+``merger_per_subject``).
 """
 import random
 import typing as tp
