@@ -95,7 +95,7 @@ def pmc_traffic(kernel_label: str):
     per MI355X_MICROARCH.md; see profiles/*pmc_summary.json).  PMC counters cannot be sampled from inside this
     process; the caller compares the summary's launch duration with the one it has just measured and marks the
     figure stale when the kernel has changed since the counters were collected."""
-    files = sorted((ROOT / "profiles").glob("*pmc_summary*.json"), key=lambda f: f.stat().st_mtime)
+    files = sorted((ROOT / "profiles").glob("*pmc_summary*.json"))      # rNx_ tags: the last name is the newest round
     if not files:
         return None, None, None
     data = json.loads(files[-1].read_text())
