@@ -211,23 +211,28 @@ class SubjectLayersFn(torch.autograd.Function):
 class ChannelMergerFn(torch.autograd.Function):
     """Spatial attention over sensors (bm/models/common.py:334-358), computed once per distinct
     sensor layout in the batch: positions_u [U, C, 2], layout_index [B] -> which layout a segment
-    uses.  ``ban`` = (centre tensor [2], radius) for the training-time sensor dropout (:342-346)."""
+    uses.  ``ban`` = (centre tensor [2], radius) for the training-time sensor dropout (:342-346).
+    ``heads`` is [O, D] (shared, the paper's configuration) or [U, O, D]: one set of heads per "layout" -- how
+    ``merger_per_subject`` runs, with one entry per (layout, subject) pair of the batch."""
 
     @staticmethod
     def forward(ctx, meg, heads, positions_u, layout_index, ban_center, ban_radius: float):
         meg, heads, positions_u = _c(meg), _c(heads), _c(positions_u)
         U, C, _ = positions_u.shape
-        O, D = heads.shape
+        O, D = heads.shape[-2:]
+        per_layout_heads = heads.dim() == 3
+        assert not per_layout_heads or heads.shape[0] == U
         emb = H.fourier_emb(positions_u, D)
         seg = torch.arange(U + 1, dtype=torch.int32, device=meg.device)
-        scores = H.gemm_nt(heads, emb, U, O, C, D, a_strides=(0, D), x_strides=(C * D, D), seg=seg,
-                           G=U, force_f32=True).view(U, O, C)
+        scores = H.gemm_nt(heads, emb, U, O, C, D, a_strides=(O * D if per_layout_heads else 0, D),
+                           x_strides=(C * D, D), seg=seg, G=U, force_f32=True).view(U, O, C)
         weights = H.masked_softmax(scores, positions_u, ban_center, ban_radius)
         widx = H.index_i32(_c(layout_index.to(torch.int64)), U)
         wp = H.pack_weights(weights, U, O, C, 1, O * C, C, 1, 0, shape=(meg.shape[2], 1))
         _, out, _ = H.conv_nn(meg, wp, O, 1, 1, widx=widx)
         ctx.save_for_backward(meg, emb, weights, layout_index, widx)
         ctx.dims = (U, C, O, D)
+        ctx.per_layout_heads = per_layout_heads
         return out
 
     @staticmethod
@@ -244,7 +249,10 @@ class ChannelMergerFn(torch.autograd.Function):
             wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0, shape=(D, 1))
             uidx = torch.arange(U, dtype=torch.int32, device=meg.device)
             _, per_layout, _ = H.conv_nn(emb, wp, O, 1, 1, widx=uidx)        # [U, O, D]
-            dheads = H.sum_over_batch(per_layout) if U > 1 else per_layout[0]
+            if ctx.per_layout_heads:
+                dheads = per_layout
+            else:
+                dheads = H.sum_over_batch(per_layout) if U > 1 else per_layout[0]
         dmeg = None
         if ctx.needs_input_grad[0]:
             wpt = H.pack_weights(weights, U, C, O, 1, O * C, 1, C, 0, shape=(T, 1))

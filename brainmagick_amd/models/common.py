@@ -396,12 +396,12 @@ class ChannelMerger(nn.Module):
                  n_subjects: int = 200, per_subject: bool = False):
         super().__init__()
         assert pos_dim % 4 == 0
-        if per_subject:
-            raise NotImplementedError("merger_per_subject is outside the MI355X hot path (unused by the paper's "
-                                      "grids, SURVEY.md §2.2)")
         self.position_getter = PositionGetter()
         self.per_subject = per_subject
-        self.heads = nn.Parameter(torch.randn(chout, pos_dim, requires_grad=True))
+        if self.per_subject:      # off the hot path (no grid of the paper sets it): one set of heads per subject
+            self.heads = nn.Parameter(torch.randn(n_subjects, chout, pos_dim, requires_grad=True))
+        else:
+            self.heads = nn.Parameter(torch.randn(chout, pos_dim, requires_grad=True))
         self.heads.data /= pos_dim ** 0.5
         self.dropout = dropout
         self.embedding = FourierEmb(pos_dim)
@@ -436,6 +436,16 @@ class ChannelMerger(nn.Module):
 
     def forward(self, meg, batch):
         positions_u, layout_index, ban_center, radius = self.layouts_and_ban(meg, batch)
+        if self.per_subject:
+            # bm/models/common.py:348-351: heads gathered per segment.  Here: one attention map per (layout, subject)
+            # pair that occurs in the batch (torch.unique: one small host round trip, off the hot path); autograd
+            # scatters the per-pair head gradients back into the [n_subjects, chout, pos_dim] parameter
+            n_subjects = self.heads.shape[0]
+            subjects = batch.subject_index.to(meg.device, torch.int64)
+            pairs, inverse = torch.unique(layout_index * n_subjects + subjects, return_inverse=True)
+            return BF.ChannelMergerFn.apply(meg, self.heads[pairs % n_subjects].contiguous(),
+                                            positions_u[pairs // n_subjects].contiguous(), inverse.contiguous(),
+                                            ban_center, radius)
         return BF.ChannelMergerFn.apply(meg, self.heads, positions_u, layout_index, ban_center,
                                         radius)
 

@@ -4,9 +4,9 @@ that ``bm/train.py:84-86`` can build it unchanged and reference checkpoints load
 forward pass is a sequence of libbmhip kernels (see ``brainmagick_amd.functional``).
 
 Options the paper's grids never use are either implemented off the hot path (GPU torch ops around the fused layer
-functions: ``dropout``, ``conv_dropout``, ``dropout_input``, ``scale``, ``rewrite``, ``post_skip``, ``merger_penalty``) or
-raise ``NotImplementedError`` at construction time (``n_fft``, ``dual_path``, ``concatenate``, ``groups``,
-``merger_per_subject``).
+functions: ``dropout``, ``conv_dropout``, ``dropout_input``, ``scale``, ``rewrite``, ``post_skip``, ``merger_penalty``,
+``merger_per_subject``) or raise ``NotImplementedError`` at construction time (``n_fft``, ``dual_path``,
+``concatenate``, ``groups``).
 """
 import random
 import typing as tp
@@ -136,7 +136,8 @@ class SimpleConv(nn.Module):
         """merger -> ONE 1x1 conv (no activation) -> subject layers: the paper's front end
         (conf/model/clip_conv.yaml: initial_depth 1, no initial_nonlin), composable into one grouped 1x1 conv."""
         return (self.merger is not None and self.subject_layers is not None and self.initial_linear is not None
-                and len(self.initial_linear) == 1 and self.subsampled_meg_channels is None)
+                and len(self.initial_linear) == 1 and self.subsampled_meg_channels is None
+                and not self.merger.per_subject)
 
     def forward(self, inputs, batch):
         subjects = batch.subject_index
