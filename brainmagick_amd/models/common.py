@@ -113,7 +113,7 @@ class ConvSequence(nn.Module):
                  activation_on_last: bool = True, post_skip: bool = False, glu: int = 0,
                  glu_context: int = 0, glu_glu: bool = True, activation: tp.Any = None) -> None:
         super().__init__()
-        unsupported = dict(stride=stride != 1, groups=groups != 1, decode=decode)
+        unsupported = dict(stride=stride != 1, decode=decode)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(
@@ -140,7 +140,7 @@ class ConvSequence(nn.Module):
             if dilation_period and (k % dilation_period) == 0:
                 dilation = 1
             pad = kernel // 2 * dilation
-            layers.append(nn.Conv1d(chin, chout, kernel, 1, pad, dilation=dilation))
+            layers.append(nn.Conv1d(chin, chout, kernel, 1, pad, dilation=dilation, groups=groups if k > 0 else 1))
             plan["conv"] = layers[-1]
             plan["dilation"] = dilation
             dilation *= dilation_growth
@@ -176,6 +176,28 @@ class ConvSequence(nn.Module):
                 self.glus.append(None)
             self._plan.append(plan)
 
+    def _grouped_layer(self, x, plan, code, leak, fused_residual):
+        """``groups`` > 1 (off the hot path: no grid of the paper sets it): conv, BatchNorm and activation are all
+        per-channel or block-diagonal, so the layer is `groups` independent layers on channel slices -- the same fused
+        functions on views of the parameters and buffers (``num_batches_tracked`` counts once)."""
+        conv, bn = plan["conv"], plan["bn"]
+        G = conv.groups
+        cin, cout = conv.in_channels // G, conv.out_channels // G
+        outs = []
+        for g in range(G):
+            xg = x[:, g * cin:(g + 1) * cin].contiguous()
+            w = conv.weight[g * cout:(g + 1) * cout]
+            b = conv.bias[g * cout:(g + 1) * cout] if conv.bias is not None else None
+            if bn is not None:
+                sl = slice(g * cout, (g + 1) * cout)
+                count = bn.num_batches_tracked if g == 0 else bn.num_batches_tracked.clone()
+                outs.append(BF.ConvBNActFn.apply(
+                    xg, w, b, bn.weight[sl], bn.bias[sl], bn.running_mean[sl], bn.running_var[sl], count,
+                    self.training, plan["dilation"], code, leak, fused_residual, bn.momentum, bn.eps))
+            else:
+                outs.append(BF.Conv1dFn.apply(xg, w, b, plan["dilation"], code, leak, False))
+        return torch.cat(outs, dim=1)
+
     def forward(self, x: tp.Any) -> tp.Any:
         for module_idx, module in enumerate(self.sequence):
             plan = self._plan[module_idx]
@@ -188,7 +210,9 @@ class ConvSequence(nn.Module):
             if plan["pre"] is not None:
                 x = plan["pre"](x)                                  # nn.Dropout on the input of the sequence
             fused_residual = residual and not plan["post"] and plan["pre"] is None
-            if plan["bn"] is not None:
+            if conv.groups != 1:
+                x = self._grouped_layer(x, plan, code, leak, fused_residual)
+            elif plan["bn"] is not None:
                 bn = plan["bn"]
                 x = BF.ConvBNActFn.apply(
                     x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,

@@ -5,8 +5,8 @@ forward pass is a sequence of libbmhip kernels (see ``brainmagick_amd.functional
 
 Options the paper's grids never use are either implemented off the hot path (GPU torch ops around the fused layer
 functions: ``dropout``, ``conv_dropout``, ``dropout_input``, ``scale``, ``rewrite``, ``post_skip``, ``merger_penalty``,
-``merger_per_subject``) or raise ``NotImplementedError`` at construction time (``n_fft``, ``dual_path``,
-``concatenate``, ``groups``).
+``merger_per_subject``, ``groups``) or raise ``NotImplementedError`` at construction time (``n_fft``, ``dual_path``,
+``concatenate``).
 """
 import random
 import typing as tp

@@ -75,12 +75,15 @@ VARIANTS = {
     # the Dropout modules shift the sequence indices (state_dict keys); eval mode: identity
     "conv_dropouts_eval": dict(cfg=variant(depth=4, conv_dropout=0.2, dropout_input=0.1, dropout=0.3),
                                training=False, n_steps=0, n_layouts=2, pad_layout=True),
+    # grouped convs from the second layer on (common.py:113-114)
+    "groups2": dict(cfg=variant(depth=4, groups=2), training=True, n_steps=1, n_layouts=2),
     # one set of attention heads per subject
     "merger_per_subject": dict(cfg=variant(depth=4, merger_per_subject=True), training=True, n_steps=1, n_layouts=2,
                                pad_layout=True),
 }
 # fixtures the CPU oracle (oracle/bm_oracle.py restates the hot path only) does not cover: HIP path vs reference directly
-OFF_PATH = ("layer_scale_rewrite_post_skip", "channel_dropout_train", "conv_dropouts_eval", "merger_per_subject")
+OFF_PATH = ("layer_scale_rewrite_post_skip", "channel_dropout_train", "conv_dropouts_eval", "merger_per_subject",
+            "groups2")
 HIDDEN = 16
 
 

@@ -60,7 +60,7 @@ def test_state_dict_contract(name):
 def test_unsupported_options_raise():
     from brainmagick_amd.models import SimpleConv
     base = dict(in_channels={"meg": 8}, out_channels=4, hidden={"meg": 8})
-    for kw in (dict(n_fft=16), dict(dual_path=1), dict(concatenate=True), dict(groups=2)):
+    for kw in (dict(n_fft=16), dict(dual_path=1), dict(concatenate=True)):
         with pytest.raises(NotImplementedError):
             SimpleConv(**{**base, "in_channels": {"meg": 8}}, **kw)
     with pytest.raises(ValueError):
