@@ -605,6 +605,30 @@ def main():
                                  "value": world * B * k2 / e2, "unit": "segments/s"}
         hip_ops.set_compute_dtype(args.dtype)
 
+    # DVFS probe (last use of this solver; never a result): the same launches, addresses and memory traffic on operands
+    # that do not toggle -- every parameter, Adam moment and input zero.  What the step gains is what the power manager
+    # takes from the matrix kernels on real data.
+    dvfs = None
+    if not args.no_side_blocks and not zero_operands:
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.zero_()
+            solver.optimizer.exp_avg.zero_()
+            solver.optimizer.exp_avg_sq.zero_()
+        hip_ops.weights_changed()
+        for sb in stream.batches:
+            sb.meg.zero_()
+            sb.features.zero_()
+        for _ in range(3):
+            cur, nxt = stream.next()
+            solver.train_step(cur, next_batch=nxt if prefetch else None)
+        e_z, loss_z = timed_steps(args.steps)
+        dvfs = {"zero_operand_ms_per_step": e_z / args.steps * 1e3, "ms_per_step": elapsed / args.steps * 1e3,
+                "ratio": elapsed / e_z, "zero_operand_loss": float(loss_z),
+                "what": "the timed loop repeated with all parameters, Adam moments and inputs zero: identical launches "
+                        "and memory traffic, operands that do not toggle; the gain is the clock the power manager "
+                        "takes away on real data"}
+
     if rank != 0:
         distrib.barrier()
         return
@@ -662,6 +686,7 @@ def main():
                      "hbm_roofline_frac_step": step_bytes / (PEAK_HBM_GBS * 1e9) / (elapsed / args.steps),
                      "algorithmic_bytes_per_step": step_bytes},
     }
+    out["dvfs_probe"] = dvfs
     out["sustained"] = sustained
     out["pcie_inclusive"] = pcie
     out["other_fp32_modes"] = other_modes or None
