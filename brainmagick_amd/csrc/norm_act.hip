@@ -88,7 +88,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, long tstride
         invstd_out[c] = invstd;
         scale_out[c] = sc;
         shift_out[c] = bt - (float)mean * sc;
-        if (running_mean) {
+        // (a batch whose statistics are not finite -- a NaN / inf in the input, which the Solver reports a few launches
+        // later through its flag word -- leaves the running estimates alone instead of poisoning them for good)
+        if (running_mean && isfinite(mean) && isfinite(var)) {
             const double unbiased = count > 1 ? var * count / (count - 1) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;

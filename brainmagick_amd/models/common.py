@@ -349,7 +349,13 @@ class PositionGetter:
             if len(self._layout_set_cache) >= 64:
                 self._layout_set_cache.pop(next(iter(self._layout_set_cache)))
             self._layout_set_cache[set_key] = positions_u
-        layout_index = torch.tensor(index, dtype=torch.int64).to(device)
+        layout_index = torch.tensor(index, dtype=torch.int64)
+        if torch.device(device).type == "cuda":
+            # pinned + asynchronous: a blocking pageable upload would make the host wait for everything queued on the
+            # stream (the previous step's backward pass) once per step with a fresh segment -> recording assignment
+            layout_index = layout_index.pin_memory().to(device, non_blocking=True)
+        else:
+            layout_index = layout_index.to(device)
         if len(self._device_cache) >= 64:
             self._device_cache.pop(next(iter(self._device_cache)))
         self._device_cache[key] = (positions_u, layout_index)

@@ -77,6 +77,9 @@ class Solver:
         self._staged: tp.Dict[int, tuple] = {}    # id(host batch) -> (host batch, device batch): see stage()
         self._copy_stream = None
         self._substituted = False
+        self._flag_ring: tp.List[torch.Tensor] = []   # pinned host copies of the device flag word (see _post_flags)
+        self._flag_i = 0
+        self._flag_ticket = None
 
     # -- bm/solver.py:243 `batch.to(self.device)` ----------------------------------------------------
     def stage(self, batch):
@@ -181,15 +184,39 @@ class Solver:
             return
         self._prefetched = (next_batch, prepared, next_batch)
 
-    def _check_flags(self):
-        """The ONE host synchronisation of a step: the device-side flag word holds "non-finite input"
-        (bm/solver.py:258-260), "ClipLoss mask not all-true" (bm/losses.py:110) and "subject / layout index out of
-        range" (the reference's `weights.gather` would have raised, bm/models/common.py:57) -- the last two raised by
-        the PREVIOUS step (``check_pending_flags()`` reads them without waiting for a next one)."""
+    def _post_flags(self):
+        """Enqueue an asynchronous read of the flag word (pinned host buffer + event) at this point of the stream:
+        ``train_step`` evaluates it right before the backward pass, when the copy -- queued behind the previous step and
+        this batch's preparation -- has long landed, instead of draining the whole queue with a blocking read in front of
+        the forward pass (which cost every step the host's run-ahead: ~0.3 ms of idle GPU while the first launches of
+        the step were being issued).  Nothing a non-finite batch could poison has happened by then: BatchNorm leaves
+        its running estimates alone on non-finite statistics, and the optimizer has not stepped."""
+        if not self.check_finite:
+            return None
+        if not self._flag_ring:
+            self._flag_ring = [torch.empty(3, dtype=torch.int32).pin_memory() for _ in range(4)]
+        buf = self._flag_ring[self._flag_i % len(self._flag_ring)]
+        self._flag_i += 1
+        buf.copy_(H.index_error_flag(self.device), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return buf, event
+
+    def _check_flags(self, ticket=None):
+        """The host's look at the device-side flag word: "non-finite input" (bm/solver.py:258-260), "ClipLoss mask not
+        all-true" (bm/losses.py:110) and "subject / layout index out of range" (the reference's `weights.gather` would
+        have raised, bm/models/common.py:57) -- the last two raised by the PREVIOUS step (``check_pending_flags()`` reads
+        them without waiting for a next one).  With a ``ticket`` (``_post_flags``) only that earlier copy is waited
+        for; without one this is a blocking read (evaluation, direct ``_process_batch`` callers)."""
         if not self.check_finite:
             return
         flag = H.index_error_flag(self.device)
-        index_err, nonfinite, bad_mask = flag.tolist()
+        if ticket is not None:
+            buf, event = ticket
+            event.synchronize()
+            index_err, nonfinite, bad_mask = buf.tolist()
+        else:
+            index_err, nonfinite, bad_mask = flag.tolist()
         if nonfinite:
             flag[1:2].zero_()
             raise AssertionError("non-finite values in the MEG or feature tensors")
@@ -205,7 +232,9 @@ class Solver:
         otherwise only read by the next one.  ``eval_step``, ``predict`` and ``state_dict`` call it."""
         self._check_flags()
 
-    def _process_batch(self, batch, training: bool = False):
+    def _process_batch(self, batch, training: bool = False, defer_flags: bool = False):
+        """bm/solver.py:230-321.  ``defer_flags`` (train_step): the asserts are posted here and evaluated before the
+        backward pass (``_post_flags``); other callers get the reference's behaviour -- they raise before the model runs."""
         pre = self._prefetched
         self._prefetched = None
         if pre is not None and pre[0] is batch:
@@ -219,7 +248,10 @@ class Solver:
             prepared = self._prepare(batch)
         if prepared is None:
             return None, None, None, None
-        self._check_flags()
+        if defer_flags:
+            self._flag_ticket = self._post_flags()
+        else:
+            self._check_flags()
         batch, meg, features, features_mask, reject_mask = prepared
         inputs = dict(meg=meg)
         estimate = self.model(inputs, batch)
@@ -268,13 +300,14 @@ class Solver:
             m.train(True)
         self.loss.train(True)
         self._substituted = False
-        estimate, output, features_mask, _ = self._process_batch(batch, training=True)
+        estimate, output, features_mask, _ = self._process_batch(batch, training=True, defer_flags=True)
         if estimate is None:
             # bm/solver.py:345-352: a fully rejected batch re-uses the last good one so that every
             # rank keeps issuing the same collectives
             if self._last_batch is None:
                 raise RuntimeError("Empty batch and last batch is none")
-            estimate, output, features_mask, _ = self._process_batch(self._last_batch, training=True)
+            estimate, output, features_mask, _ = self._process_batch(self._last_batch, training=True,
+                                                                     defer_flags=True)
         elif not self._substituted:
             self._last_batch = batch
         output, target_offset, valid = self._candidates(output)
@@ -287,6 +320,9 @@ class Solver:
         for mod in self.model.modules():
             if hasattr(mod, "training_penalty"):
                 loss = loss + mod.training_penalty.to(loss.device)
+        # the asserts of bm/solver.py:258-260 (this batch) and of the previous step: before anything is updated
+        ticket, self._flag_ticket = self._flag_ticket, None
+        self._check_flags(ticket)
         self.optimizer.zero_grad(set_to_none=True)
         with self.optimizer.writing_grads():       # the weight-gradient kernels write straight into the flat bucket
             loss.backward()
