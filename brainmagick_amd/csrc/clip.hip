@@ -229,6 +229,72 @@ extern "C" int bm_clip_ce_masked(const float* part, int nsplit, const float* inv
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column softmax (the "audio -> brain" direction of the symmetric CLIP objective; an opt-in extension, the
+// reference's ClipLoss is the row term alone, bm/losses.py:104-114).  For every target candidate o = off + j the
+// column scores[:, o] is a B-way classification over the estimates with the answer in row j:
+//     loss_col[j] = logsumexp_b scores[b][o] - scores[j][o]
+// and the combined gradient  dscaled = w_row * dscaled_row + w_col * (softmax_col - onehot) / B * inv_norm[o]
+// is written over the row term in place (candidates that are negatives only keep w_row * their row term).
+// One wavefront per column, lanes over the rows (the matrix is L2-resident: B * B' * 4 bytes), shuffle reductions.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clip_ce_cols_kernel(const float* __restrict__ scores,
+                                                           const float* __restrict__ inv_norm,
+                                                           float* __restrict__ dscaled, float* __restrict__ loss_col,
+                                                           int B, int Bc, int off, float w_row, float w_col) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= Bc) return;
+    const int j = o - off;
+    if (j < 0 || j >= B) {                       // a negative without a label: only the weight of the row term
+        if (dscaled) for (int b = lane; b < B; b += 64) dscaled[(long)b * Bc + o] *= w_row;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int b = lane; b < B; b += 64) mx = fmaxf(mx, scores[(long)b * Bc + o]);
+    mx = bm_wave_max(mx);
+    float sum = 0.f;
+    for (int b = lane; b < B; b += 64) sum += expf(scores[(long)b * Bc + o] - mx);
+    sum = bm_wave_sum(sum);
+    const float lse = mx + logf(sum);
+    if (lane == 0 && loss_col) loss_col[j] = lse - scores[(long)j * Bc + o];
+    if (!dscaled) return;
+    const float inv = 1.f / sum;
+    const float g = w_col / (float)B * inv_norm[o];
+    for (int b = lane; b < B; b += 64) {
+        const float pr = expf(scores[(long)b * Bc + o] - mx) * inv;
+        const long at = (long)b * Bc + o;
+        dscaled[at] = fmaf(w_row, dscaled[at], g * (pr - (b == j ? 1.f : 0.f)));
+    }
+}
+
+// loss <- w_row * loss + w_col * mean(loss_col)
+__global__ void clip_mix_loss_kernel(const float* __restrict__ loss_col, int n, float* __restrict__ loss,
+                                     float w_row, float w_col) {
+    __shared__ double sh[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += loss_col[i];
+    s = bm_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = w_row * *loss + w_col * (float)((sh[0] + sh[1] + sh[2] + sh[3]) / n);
+}
+
+// scores [B][Bc] as written by bm_clip_ce; dscaled (nullable) holds the row term and is updated in place; loss
+// (nullable) holds the row loss and becomes the weighted sum.  loss_col: [B] scratch / per-column losses.
+extern "C" int bm_clip_ce_cols(const float* scores, const float* inv_norm, float* dscaled, float* loss_col,
+                               float* loss, int B, int Bc, int target_offset, float w_row, float w_col,
+                               void* stream) {
+    BM_REQUIRE(scores && inv_norm && loss_col, "clip_ce_cols: null pointer");
+    BM_REQUIRE(target_offset >= 0 && target_offset + B <= Bc, "clip_ce_cols: need at least as many targets as estimates");
+    if (B == 0) return BM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(clip_ce_cols_kernel, dim3((Bc + 3) / 4), dim3(256), 0, s, scores, inv_norm, dscaled,
+                       loss_col, B, Bc, target_offset, w_row, w_col);
+    if (loss) hipLaunchKernelGGL(clip_mix_loss_kernel, dim3(1), dim3(256), 0, s, loss_col, B, loss, w_row, w_col);
+    return bm_check_launch("clip_ce_cols");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Retrieval evaluation (scripts/run_eval_probs.py:237-264 _get_accuracy_from_probs; bm/wer.py:104-111):
 // top-k columns of every probability / score row and "is the row's label among the labels of its
 // top-k candidates".  One wavefront per row; k selection passes, each a strided scan + wave arg-max

@@ -383,10 +383,11 @@ def _clip_raw_scores(estimate, candidate, B, Bc, K):
 class ClipLossFn(torch.autograd.Function):
     """ClipLoss.forward (bm/losses.py:104-114): scores = est . cand^T * inv_norm (split-K MFMA GEMM
     over K = F*T), row-wise cross entropy with the target on the diagonal; the backward is a second
-    MFMA GEMM dEst = dScores . cand."""
+    MFMA GEMM dEst = dScores . cand.  ``symmetric`` (extension, off = the reference): the loss is the mean of the
+    row term and the column term (every target candidate classifies the estimates, `bm_clip_ce_cols`)."""
 
     @staticmethod
-    def forward(ctx, estimate, candidate, target_offset: int = 0, col_valid=None):
+    def forward(ctx, estimate, candidate, target_offset: int = 0, col_valid=None, symmetric: bool = False):
         estimate, candidate = _c(estimate), _c(candidate)
         B, Bc = estimate.shape[0], candidate.shape[0]
         K = estimate.numel() // B
@@ -395,6 +396,8 @@ class ClipLossFn(torch.autograd.Function):
         part = _clip_raw_scores(estimate, candidate, B, Bc, K)
         scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True,
                                              target_offset=target_offset, col_valid=col_valid)
+        if symmetric:
+            H.clip_ce_cols(scores, inv, dscaled, loss, target_offset=target_offset)
         if ctx.needs_input_grad[1]:
             ctx.save_for_backward(candidate, dscaled, estimate, scores, inv)
         else:
@@ -434,7 +437,7 @@ class ClipLossFn(torch.autograd.Function):
             coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
             H.row_axpy_sub(dcand, cand2, coef)
             dcand = dcand.view(ctx.cand_shape)
-        return dest, dcand, None, None
+        return dest, dcand, None, None, None
 
 
 def clip_scores(estimate, candidate, want_probs=False):

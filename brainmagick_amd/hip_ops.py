@@ -840,6 +840,18 @@ def clip_ce(part, inv_norm, want_probs=False, want_grad=False, want_loss=False,
     return scores, probs, dscaled, loss
 
 
+def clip_ce_cols(scores, inv_norm, dscaled, loss, target_offset: int = 0, w_row: float = 0.5, w_col: float = 0.5):
+    """Column term of the symmetric objective on top of ``clip_ce``'s outputs: ``dscaled`` (row term) and ``loss``
+    (row loss) are updated in place to the weighted sums; returns the per-target column losses [B]."""
+    _req(scores, "clip_ce_cols.scores")
+    B, Bc = scores.shape
+    loss_col = torch.empty(B, device=scores.device, dtype=torch.float32)
+    check(lib().bm_clip_ce_cols(_p(scores), _p(_req(inv_norm, "inv_norm")), _p(_opt(dscaled, "dscaled")),
+                                _p(loss_col), _p(_opt(loss, "loss")), B, Bc, target_offset, w_row, w_col, _stream()),
+          "bm_clip_ce_cols")
+    return loss_col
+
+
 def clip_cand_coef(dscaled, scores, inv_norm, alpha=None) -> torch.Tensor:
     _req(dscaled, "clip_cand_coef.dscaled")
     _req(scores, "clip_cand_coef.scores")

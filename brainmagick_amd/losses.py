@@ -15,8 +15,11 @@ class ClipLoss(torch.nn.Module):
     ``self.linear = None`` (losses.py:35) and only tests that attribute (losses.py:82)."""
 
     def __init__(self, linear=None, twin=True, pool=False, tmin=None, tmax=None,
-                 tmin_train=None, tmax_train=None, dset_args=None, center=False):
+                 tmin_train=None, tmax_train=None, dset_args=None, center=False, symmetric=False):
         super().__init__()
+        # extension (default off = the reference): add the column term of the CLIP objective, loss =
+        # (CE over each estimate's row + CE over each target candidate's column) / 2
+        self.symmetric = symmetric
         self.linear = None
         self.pool = pool
         self.center = center
@@ -96,4 +99,4 @@ class ClipLoss(torch.nn.Module):
         assert estimate.size(0) + target_offset <= candidate.size(0), \
             "need at least as many targets as estimates"
         estimate, candidate = self._prepare(estimate, candidate)
-        return BF.ClipLossFn.apply(estimate, candidate, target_offset, candidate_valid)[0]
+        return BF.ClipLossFn.apply(estimate, candidate, target_offset, candidate_valid, self.symmetric)[0]

@@ -236,6 +236,14 @@ int bm_clip_ce_masked(const float* part, int nsplit, const float* inv_norm, cons
                       float* probs, float* dscaled, float* loss_row, float* loss, int B, int Bc, int target_offset,
                       void* stream);
 
+/* Column term of the symmetric CLIP objective (opt-in extension named by the hot-path contract, "row/col softmax";
+ * the reference computes the row term only, bm/losses.py:104-114): for every target candidate o = target_offset + j,
+ * loss_col[j] = logsumexp_b scores[b][o] - scores[j][o].  dscaled (nullable; holds bm_clip_ce's row term) becomes
+ * w_row * row term + w_col * (softmax over the column - onehot) / B * inv_norm[o] in place; loss (nullable; holds the
+ * row loss) becomes w_row * loss + w_col * mean(loss_col). */
+int bm_clip_ce_cols(const float* scores, const float* inv_norm, float* dscaled, float* loss_col, float* loss, int B,
+                    int Bc, int target_offset, float w_row, float w_col, void* stream);
+
 /* Gradient of ClipLoss w.r.t. the candidates (learnable feature model, bm/solver.py:304-320):
  * coef[o] = alpha * (sum_b dscaled[b,o]*scores[b,o]) / |cand_o| ;  y[r] -= coef[r] * x[r]. */
 int bm_clip_cand_coef(const float* dscaled, const float* scores, const float* inv_norm,

@@ -326,6 +326,18 @@ def clip_loss(estimate: torch.Tensor, candidate: torch.Tensor, **kw) -> torch.Te
     return F.cross_entropy(scores, target)
 
 
+def clip_loss_symmetric(estimate: torch.Tensor, candidate: torch.Tensor, target_offset: int = 0, **kw) -> torch.Tensor:
+    """NOT in the reference (its ClipLoss is the row term, bm/losses.py:104-114): the symmetric CLIP objective the
+    hot-path contract names ("row/col softmax"), restated here as the checker of the opt-in ``symmetric`` extension.
+    Row term as ``clip_loss``; column term: every target candidate classifies the B estimates."""
+    scores = clip_scores(estimate, candidate, **kw)
+    n = len(scores)
+    target = torch.arange(n)
+    rows = F.cross_entropy(scores, target + target_offset)
+    cols = F.cross_entropy(scores[:, target_offset:target_offset + n].t(), target)
+    return 0.5 * (rows + cols)
+
+
 def topk_accuracy(probs: torch.Tensor, labels: torch.Tensor, row_labels: torch.Tensor,
                   topk: int = 10) -> float:
     """scripts/run_eval_probs.py:237-264 _get_accuracy_from_probs, segment-level: a row is a hit

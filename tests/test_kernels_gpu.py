@@ -435,6 +435,33 @@ def test_clip_loss_candidate_gradients(B, Bc):
     assert rel_l2(cg.grad, cand.grad) < GRAD_TOL
 
 
+@pytest.mark.parametrize("B,Bc,off", [(48, 48, 0), (40, 100, 0), (32, 128, 64), (256, 256, 0), (300, 301, 1)])
+def test_symmetric_clip_loss(B, Bc, off):
+    """The opt-in column term (``ClipLoss(symmetric=True)``: "row/col softmax" of the hot-path contract; the
+    reference has the row term only): loss and gradients w.r.t. estimates AND candidates against the fp64
+    restatement, with extra negatives and with the targets at an offset (a rank's block of gathered candidates)."""
+    from brainmagick_amd.losses import ClipLoss
+    g = _gen(B + 3 * Bc + off)
+    est = torch.randn(B, 7, 30, generator=g, dtype=torch.float64, requires_grad=True)
+    cand = (torch.randn(Bc, 7, 30, generator=g, dtype=torch.float64) * 1.5).requires_grad_(True)
+    with torch.no_grad():
+        est += 0.05 * cand[off:off + B]
+    ref = O.clip_loss_symmetric(est, cand, target_offset=off)
+    (ref * 1.3).backward()
+    eg = est.detach().float().cuda().requires_grad_(True)
+    cg = cand.detach().float().cuda().requires_grad_(True)
+    mask = torch.ones(B, 1, 30, dtype=torch.bool, device="cuda")
+    loss = ClipLoss(symmetric=True).cuda()(eg, cg, mask, target_offset=off)
+    (loss * 1.3).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5, (float(loss), float(ref))
+    assert rel_l2(eg.grad, est.grad) < GRAD_TOL
+    assert rel_l2(cg.grad, cand.grad) < GRAD_TOL
+    # and the default stays the reference's row term
+    rows = ClipLoss().cuda()(eg.detach(), cg.detach(), mask, target_offset=off)
+    ref_rows = F.cross_entropy(O.clip_scores(est.detach(), cand.detach()), torch.arange(B) + off)
+    assert abs(float(rows) - float(ref_rows)) < 1e-5
+
+
 @pytest.mark.parametrize("n_neg", [None, 40])
 def test_word_level_wer_batched(H, n_neg):
     """retrieval.get_wer (one GEMM + row kernels) vs the reference's per-segment loop (bm/wer.py:91-120)."""

@@ -148,3 +148,17 @@ def test_mne_layout_branch_matches_the_reference(monkeypatch):
     assert getter.get_recording_layout(rec) is got                       # cached per recording_index
     assert getter._invalid_names == {"UADC001", "STIM"}
     assert int(getter.is_invalid(got).sum()) == 2
+
+
+def test_symmetric_restatement_is_the_mean_of_the_two_directions():
+    """`O.clip_loss_symmetric` (the checker of the opt-in column term; the reference has none) against plain loops."""
+    g = torch.Generator().manual_seed(3)
+    B, Bc, off = 5, 9, 2
+    est = torch.randn(B, 3, 4, generator=g, dtype=torch.float64)
+    cand = torch.randn(Bc, 3, 4, generator=g, dtype=torch.float64)
+    s = O.clip_scores(est, cand)
+    rows = sum(torch.logsumexp(s[b], 0) - s[b, off + b] for b in range(B)) / B
+    cols = sum(torch.logsumexp(s[:, off + j], 0) - s[j, off + j] for j in range(B)) / B
+    assert float(O.clip_loss_symmetric(est, cand, target_offset=off)) == pytest.approx(float(0.5 * (rows + cols)), abs=1e-12)
+    assert float(O.clip_loss(est, cand)) == pytest.approx(
+        float(sum(torch.logsumexp(s[b], 0) - s[b, b] for b in range(B)) / B), abs=1e-12)
