@@ -484,3 +484,41 @@ def pad_multiple(x: torch.Tensor, base: int):
     length = x.shape[-1]
     target = math.ceil(length / base) * base
     return torch.nn.functional.pad(x, (0, target - length))
+
+
+class DualPathRNN(nn.Module):
+    """``dual_path`` of SimpleConv (bm/models/common.py:154-180): ``4 * depth`` single-layer LSTMs over the time axis,
+    each added to its input.  Off the hot path (no grid of the paper switches it on): the recurrences are torch's
+    own GPU LSTM (the composite ATen implementation, not the vendor RNN library: deterministic and always present);
+    module names and initialisation are the reference's, so its checkpoints load.
+
+    What the reference computes, restated (``test_against_reference_golden[dual_path]`` pins it): every LSTM runs
+    over the WHOLE zero-padded sequence (the reference folds the sequence into chunks of ``inner_length`` but feeds
+    the unfolded one, common.py:166-171); after the even-numbered LSTMs the output's time steps are re-ordered as if
+    it were the folded one (step ``i * n + j`` moves to ``j * inner_length + i``, n = chunks), and the sequence is
+    reversed after every odd-numbered one."""
+
+    def __init__(self, channels: int, depth: int, inner_length: int = 10):
+        super().__init__()
+        self.lstms = nn.ModuleList([nn.LSTM(channels, channels, 1) for _ in range(depth * 4)])
+        self.inner_length = inner_length
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        length = x.shape[-1]
+        seq = pad_multiple(x, self.inner_length).permute(2, 0, 1).contiguous()          # [L', B, C]
+        steps, batch, channels = seq.shape
+        chunks = steps // self.inner_length
+        vendor_rnn = torch.backends.cudnn.enabled
+        torch.backends.cudnn.enabled = False
+        try:
+            for k, lstm in enumerate(self.lstms):
+                out = lstm(seq)[0]
+                if k % 2 == 0:
+                    out = out.view(self.inner_length, chunks, batch, channels).transpose(0, 1) \
+                        .reshape(steps, batch, channels)
+                seq = seq + out
+                if k % 2 == 1:
+                    seq = seq.flip(0)
+        finally:
+            torch.backends.cudnn.enabled = vendor_rnn
+        return seq[:length].permute(1, 2, 0).contiguous()

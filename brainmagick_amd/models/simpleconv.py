@@ -5,8 +5,9 @@ forward pass is a sequence of libbmhip kernels (see ``brainmagick_amd.functional
 
 Options the paper's grids never use are either implemented off the hot path (GPU torch ops around the fused layer
 functions: ``dropout``, ``conv_dropout``, ``dropout_input``, ``scale``, ``rewrite``, ``post_skip``, ``merger_penalty``,
-``merger_per_subject``, ``groups``) or raise ``NotImplementedError`` at construction time (``n_fft``, ``dual_path``,
-``concatenate``).
+``merger_per_subject``, ``groups``, more inputs than ``meg`` with or without ``concatenate``) or raise
+``NotImplementedError`` at construction time (``n_fft``).  ``dual_path`` runs torch's GPU LSTM
+between the stack and the head.
 """
 import random
 import typing as tp
@@ -15,7 +16,7 @@ import torch
 from torch import nn
 
 from .common import (
-    ConvSequence, ScaledEmbedding, SubjectLayers, ChannelMerger, ChannelDropout, make_activation)
+    ConvSequence, ScaledEmbedding, SubjectLayers, ChannelMerger, ChannelDropout, DualPathRNN, make_activation)
 from .. import functional as BF
 from .. import hip_ops as H
 
@@ -49,19 +50,21 @@ class SimpleConv(nn.Module):
         if set(in_channels) != set(hidden):
             raise ValueError("Channels and hidden keys must match "
                              f"({set(in_channels.keys())} and {set(hidden.keys())})")
-        rejected = [name for name, used in dict(
-            concatenate=concatenate, dual_path=bool(dual_path), n_fft=n_fft is not None,
-            multi_input=set(in_channels) != {"meg"}).items() if used]
-        if rejected:
+        if n_fft is not None:
             raise NotImplementedError(
-                f"SimpleConv options {rejected} are outside the MI355X hot path (STFT / DualPathRNN / "
-                "multi-input are unused by the paper's grids, SURVEY.md §2.2)")
+                "SimpleConv option n_fft (torchaudio STFT front end) is outside the MI355X hot path: no grid of the "
+                "paper uses it (SURVEY.md §2.2), and torchaudio being absent from this image the reference itself "
+                "cannot run it here, so there would be nothing to hold an implementation to")
+        if "meg" not in in_channels:
+            raise ValueError("SimpleConv needs a 'meg' input (the sensor front end is built around it)")
         if kernel_size % 2 != 1:
             raise AssertionError("For padding to work, this must be verified")       # reference message
         if linear_out and complex_out:
             raise AssertionError("linear_out and complex_out are exclusive")
         self.out_channels = out_channels
+        self._concatenate = concatenate
         activation = make_activation(gelu, relu_leakiness)
+        in_channels, hidden = dict(in_channels), dict(hidden)      # (the reference edits its caller's dict)
 
         width = in_channels["meg"]
         self.dropout = ChannelDropout(dropout, dropout_rescale) if dropout > 0. else None   # simpleconv.py:103-104
@@ -76,24 +79,32 @@ class SimpleConv(nn.Module):
             subject=dict(layers=subject_layers, where=subject_layers_dim, init_id=subject_layers_id,
                          emb_dim=subject_dim, emb_scale=embedding_scale))
 
-        # conv stack and head; without a head the last conv of the stack produces the output channels
-        widths = [width] + [int(round(hidden["meg"] * growth ** k)) for k in range(depth)]
+        # one conv stack per input (or one over the channel-wise concatenation of all inputs, simpleconv.py:138-147)
+        # and the head; without a head the last conv of the single stack produces the output channels
+        in_channels["meg"] = width
+        if concatenate:
+            in_channels = {"concat": sum(in_channels.values())}
+            hidden = {"concat": sum(hidden.values())}
+        widths = {name: [in_channels[name]] + [int(round(hidden[name] * growth ** k)) for k in range(depth)]
+                  for name in in_channels}
         stack_kw = dict(kernel=kernel_size, stride=1, leakiness=relu_leakiness, dropout=conv_dropout,
                         dropout_input=dropout_input, batch_norm=batch_norm, dilation_growth=dilation_growth,
                         groups=groups, dilation_period=dilation_period, skip=skip, post_skip=post_skip,
                         scale=scale, rewrite=rewrite, glu=glu, glu_context=glu_context, glu_glu=glu_glu,
                         activation=activation)
-        top = widths[-1]
+        top = sum(w[-1] for w in widths.values())
+        self.dual_path = DualPathRNN(top, dual_path) if dual_path else None       # simpleconv.py:163-165
         if linear_out:
             self.final = nn.ConvTranspose1d(top, out_channels, 1, 1, 0)
         elif complex_out:
             self.final = nn.Sequential(nn.Conv1d(top, 2 * top, 1), activation(),
                                        nn.ConvTranspose1d(2 * top, out_channels, 1, 1, 0))
         else:
+            assert len(widths) == 1, "if no linear_out, there must be a single branch."      # reference message
             self.final = None
             stack_kw["activation_on_last"] = False
-            widths[-1] = out_channels
-        self.encoders = nn.ModuleDict({"meg": ConvSequence(widths, **stack_kw)})
+            next(iter(widths.values()))[-1] = out_channels
+        self.encoders = nn.ModuleDict({name: ConvSequence(w, **stack_kw) for name, w in widths.items()})
 
     def _subsample(self, n_sensors: int, keep_n: int):
         """`subsample_meg_channels`: a fixed pseudo-random subset of sensors (seed 1234, simpleconv.py:95-100)
@@ -141,7 +152,7 @@ class SimpleConv(nn.Module):
 
     def forward(self, inputs, batch):
         subjects = batch.subject_index
-        length = inputs["meg"].shape[-1]
+        length = next(iter(inputs.values())).shape[-1]
         x = inputs["meg"]
         if not x.is_cuda:
             raise RuntimeError("brainmagick_amd.SimpleConv runs on the MI355X HIP path only; got a "
@@ -188,7 +199,14 @@ class SimpleConv(nn.Module):
             x = torch.cat([x, emb.expand(-1, -1, length)], dim=1)
         inputs["meg"] = x                                     # the reference reassigns the dict entry
 
-        x = self.encoders["meg"](x)
+        if self._concatenate:                                 # inputs side by side, in the order of their names
+            x = self.encoders["concat"](torch.cat([v for _, v in sorted(inputs.items())], dim=1))
+        elif len(self.encoders) == 1:
+            x = self.encoders["meg"](x)
+        else:
+            x = torch.cat([self.encoders[name](v) for name, v in sorted(inputs.items())], dim=1)
+        if self.dual_path is not None:
+            x = self.dual_path(x)
         if self.final is not None:
             if isinstance(self.final, nn.ConvTranspose1d):
                 x = BF.Conv1dFn.apply(x, self.final.weight, self.final.bias, 1, H.ACT_NONE, 0., True)

@@ -80,10 +80,20 @@ VARIANTS = {
     # one set of attention heads per subject
     "merger_per_subject": dict(cfg=variant(depth=4, merger_per_subject=True), training=True, n_steps=1, n_layouts=2,
                                pad_layout=True),
+    # a second input next to the sensors: one conv stack per input, outputs side by side into the head
+    # (simpleconv.py:149-176,228-234) ...
+    "two_inputs": dict(cfg=variant(depth=4), training=True, n_steps=1, n_layouts=2,
+                       extra_inputs={"aux": 6}, extra_hidden={"aux": 8}),
+    # ... or the inputs side by side into one stack (`concatenate`, simpleconv.py:143-147,223-226)
+    "two_inputs_concatenate": dict(cfg=variant(depth=4, concatenate=True, complex_out=False, linear_out=True),
+                                   training=True, n_steps=1, n_layouts=2,
+                                   extra_inputs={"aux": 6}, extra_hidden={"aux": 8}),
+    # the LSTM stack between the conv stack and the head (simpleconv.py:163-165,236-237; T = 48 is padded to 50)
+    "dual_path": dict(cfg=variant(depth=4, dual_path=1), training=True, n_steps=1, n_layouts=2),
 }
 # fixtures the CPU oracle (oracle/bm_oracle.py restates the hot path only) does not cover: HIP path vs reference directly
 OFF_PATH = ("layer_scale_rewrite_post_skip", "channel_dropout_train", "conv_dropouts_eval", "merger_per_subject",
-            "groups2")
+            "groups2", "two_inputs", "two_inputs_concatenate", "dual_path")
 HIDDEN = 16
 
 
@@ -118,10 +128,12 @@ def run_variant(name, spec, sc, common, losses):
         candidates = torch.cat([candidates, torch.randn(n_neg, SMALL["F"], SMALL["T"],
                                                         generator=gen)])
     ban_center = torch.rand(2, generator=gen)
+    extra_inputs = {k: torch.randn(SMALL["B"], ch, SMALL["T"], generator=gen)
+                    for k, ch in spec.get("extra_inputs", {}).items()}
 
     torch.manual_seed(seed)
-    model = sc.SimpleConv(in_channels={"meg": SMALL["C"]}, out_channels=SMALL["F"],
-                          hidden={"meg": HIDDEN}, n_subjects=SMALL["S"], **cfg)
+    model = sc.SimpleConv(in_channels={"meg": SMALL["C"], **spec.get("extra_inputs", {})}, out_channels=SMALL["F"],
+                          hidden={"meg": HIDDEN, **spec.get("extra_hidden", {})}, n_subjects=SMALL["S"], **cfg)
     # non-trivial BN affine / running stats so that eval mode and BN grads are exercised
     with torch.no_grad():
         for mod in model.modules():
@@ -145,7 +157,11 @@ def run_variant(name, spec, sc, common, losses):
         return real_rand(*a, **k)
 
     out = {"meta": json.dumps(dict(cfg=cfg, hidden=HIDDEN, training=training, **SMALL,
-                                   n_steps=spec["n_steps"], torch=torch.__version__))}
+                                   n_steps=spec["n_steps"], torch=torch.__version__,
+                                   extra_inputs=spec.get("extra_inputs", {}),
+                                   extra_hidden=spec.get("extra_hidden", {})))}
+    for k, v in extra_inputs.items():
+        out[f"in/{k}"] = v.numpy().copy()
     for k, v in model.state_dict().items():
         out[f"sd0/{k}"] = v.detach().clone().numpy()
     out["in/meg"] = sb.meg.numpy().copy()
@@ -159,7 +175,7 @@ def run_variant(name, spec, sc, common, losses):
         losses_seen = []
         steps = max(spec["n_steps"], 1)
         for step in range(steps):
-            inputs = {"meg": sb.meg.clone()}
+            inputs = {"meg": sb.meg.clone(), **{k: v.clone() for k, v in extra_inputs.items()}}
             mask = torch.ones(len(sb.meg), 1, SMALL["T"], dtype=torch.bool)
             if training and spec["n_steps"]:
                 estimate = model(inputs, batch)
@@ -370,10 +386,17 @@ def mne_layout_fixture(common):
             "ch_names": np.array(ch_names), "positions": positions.numpy().copy()}
 
 
-def main():
+def main(only=()):
+    """`python make_golden.py` regenerates everything; `python make_golden.py <variant> ...` only those models."""
+    sc, common, losses = load_reference()
+    if only:
+        for name in only:
+            out = run_variant(name, VARIANTS[name], sc, common, losses)
+            np.savez_compressed(HERE / f"{name}.npz", **out)
+            print(f"{name}: losses={out['out/losses']}")
+        return
     np.savez_compressed(HERE / "scale_reject.npz", **scale_reject_fixture())
     print("scale_reject: done")
-    sc, common, losses = load_reference()
     for name, spec in VARIANTS.items():
         out = run_variant(name, spec, sc, common, losses)
         np.savez_compressed(HERE / f"{name}.npz", **out)
@@ -387,4 +410,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

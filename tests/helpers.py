@@ -14,7 +14,8 @@ MODEL_FIXTURES = ["clip_conv_train", "clip_conv_eval", "no_merger_relu_noskip",
 # options outside the paper's grids, implemented off the hot path (GPU torch ops + the 1x1 HIP conv): the HIP model is
 # held to the live reference directly (the CPU oracle restates the hot path only)
 OFF_PATH_FIXTURES = ["layer_scale_rewrite_post_skip", "channel_dropout_train", "conv_dropouts_eval",
-                     "merger_per_subject", "groups2"]
+                     "merger_per_subject", "groups2", "two_inputs", "two_inputs_concatenate",
+                     "dual_path"]
 
 
 class Golden:

@@ -45,8 +45,9 @@ def test_state_dict_contract(name):
     sd0 = g.group("sd0")
     seed = 2036 + sum(map(ord, name))            # tests/golden/make_golden.py
     torch.manual_seed(seed)
-    model = SimpleConv(in_channels={"meg": meta["C"]}, out_channels=meta["F"],
-                       hidden={"meg": meta["hidden"]}, n_subjects=meta["S"], **meta["cfg"])
+    model = SimpleConv(in_channels={"meg": meta["C"], **meta.get("extra_inputs", {})}, out_channels=meta["F"],
+                       hidden={"meg": meta["hidden"], **meta.get("extra_hidden", {})}, n_subjects=meta["S"],
+                       **meta["cfg"])
     sd = model.state_dict()
     assert list(sd.keys()) == list(sd0.keys())
     bn_prefixes = {k.rsplit(".", 1)[0] for k in sd if k.endswith(".running_mean")}
@@ -60,11 +61,15 @@ def test_state_dict_contract(name):
 def test_unsupported_options_raise():
     from brainmagick_amd.models import SimpleConv
     base = dict(in_channels={"meg": 8}, out_channels=4, hidden={"meg": 8})
-    for kw in (dict(n_fft=16), dict(dual_path=1), dict(concatenate=True)):
+    for kw in (dict(n_fft=16),):
         with pytest.raises(NotImplementedError):
             SimpleConv(**{**base, "in_channels": {"meg": 8}}, **kw)
     with pytest.raises(ValueError):
         SimpleConv(in_channels={"meg": 8}, out_channels=4, hidden={"eeg": 8})
+    with pytest.raises(ValueError):
+        SimpleConv(in_channels={"eeg": 8}, out_channels=4, hidden={"eeg": 8})
+    with pytest.raises(AssertionError):          # two stacks need a head to merge them (reference assert)
+        SimpleConv(in_channels={"meg": 8, "aux": 2}, out_channels=4, hidden={"meg": 8, "aux": 4})
 
 
 def test_no_cpu_fallback():
