@@ -118,7 +118,7 @@ def conv_mpad(M: int) -> int:
     return lib().bm_conv_mpad(M)
 
 
-AMAX_SHARDS = 8       # an amax slot is 8 floats (shards of the atomic maximum, see csrc/bm_common.h); max|x| = slot.max()
+AMAX_SHARDS = 8       # an amax slot is 8 floats (csrc/bm_common.h; the finalize kernels write all eight); max|x| = slot.max()
 amax_scans = 0        # number of stand-alone amax passes launched (producers that publish their own maximum need none)
 
 
@@ -166,7 +166,7 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
         return None
     pool = _amax_pool.get(t.device)
     if pool is None or pool[1] >= pool[0].numel():
-        # zeroed: the producers raise their slot with atomic max (one fill per 4 096 slots)
+        # one zero fill per 4 096 slots (a slot nobody finalized reads as max|x| = 0)
         pool = _amax_pool[t.device] = [torch.zeros(4096 * AMAX_SHARDS, device=t.device, dtype=torch.float32), 0]
     slot = pool[0][pool[1]:pool[1] + AMAX_SHARDS]
     pool[1] += AMAX_SHARDS
@@ -176,7 +176,7 @@ def _amax_slot(t: torch.Tensor) -> tp.Optional[torch.Tensor]:
 
 def _row_amax_out(t: torch.Tensor, slot) -> tp.Optional[torch.Tensor]:
     """[channels] fp32 buffer for a producer with a (channel, split) grid to publish max|t| PER CHANNEL into (next to the
-    tensor slot; two-stage amax mode only).  A gradient channel is a row of the weight gradient: the f16x2 weight-gradient
+    tensor slot).  A gradient channel is a row of the weight gradient: the f16x2 weight-gradient
     kernel then scales A row by row (csrc/gemm_nt_h2w.hip, RS kernels), so a channel far below its tensor's maximum keeps
     its 22 bits.  Attached to the tensor like the slot."""
     if slot is None:
