@@ -192,7 +192,8 @@ def _paper_model(C, F, S, seed=0):
                       **O.CLIP_CONV_CFG)
 
 
-@pytest.mark.parametrize("cfg_name,B,T", [("cfg2", 8, 360), ("cfg5", 6, 343), ("cfg1", 4, 361)])
+@pytest.mark.parametrize("cfg_name,B,T", [("cfg2", 8, 360), ("cfg5", 6, 343), ("cfg1", 4, 361), ("cfg2", 3, 777),
+                                          ("cfg2", 5, 130)])
 def test_paper_model_step_against_oracle(cfg_name, B, T):
     """Full clip_conv architecture (9-16 M parameters) at reduced batch vs the CPU oracle: loss,
     estimate, every gradient, and the parameters after two Adam steps."""
