@@ -363,7 +363,11 @@ __global__ void clip_cand_coef_kernel(const float* __restrict__ dscaled, const f
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= Bc) return;
     double r = 0;
-    for (int b = 0; b < B; ++b) r += (double)dscaled[(long)b * Bc + o] * (double)scores[(long)b * Bc + o];
+    // a masked candidate (bm_clip_ce_masked) carries score -inf and gradient 0: its terms are skipped, 0 * -inf is NaN
+    for (int b = 0; b < B; ++b) {
+        const float d = dscaled[(long)b * Bc + o];
+        if (d != 0.f) r += (double)d * (double)scores[(long)b * Bc + o];
+    }
     const float norm = 1.0f / inv_norm[o] - 1e-8f;
     const float a = alpha ? *alpha : 1.f;
     coef[o] = norm > 0.f ? a * (float)r / norm : 0.f;

@@ -523,7 +523,10 @@ class CandidateGather:
         self._B = 0
         self._valid = None
 
-    def start(self, candidates: torch.Tensor, block_rows: tp.Optional[int] = None):
+    def start(self, candidates: torch.Tensor, block_rows: tp.Optional[int] = None, verify_block: bool = False):
+        """``verify_block``: the caller derived ``block_rows`` from its LOCAL batch (not from the configuration), so
+        ranks may disagree (the short last batch of an epoch, an unbalanced sampler): agree on it with a tiny all-reduce
+        before the sized collective is issued -- an all-gather with unequal blocks hangs or corrupts."""
         self._valid = None
         if not is_distributed():
             self._out = candidates
@@ -532,7 +535,7 @@ class CandidateGather:
         n = candidates.shape[0]
         self._B = n if block_rows is None else block_rows
         assert n <= self._B, (n, self._B)
-        if os.environ.get("BM_CHECK_RANKS", "0") == "1":
+        if verify_block or os.environ.get("BM_CHECK_RANKS", "0") == "1":
             check_equal_over_ranks(self._B * (candidates.numel() // max(n, 1)), "candidate block size")
         candidates = candidates.contiguous()
         side = self.stream if (self.stream is not None and candidates.is_cuda) else None

@@ -184,13 +184,16 @@ class ConvSequence(nn.Module):
         G = conv.groups
         cin, cout = conv.in_channels // G, conv.out_channels // G
         outs = []
+        # snapshot of the counter BEFORE group 0 increments it: with momentum=None (cumulative average) every group
+        # must see the same count
+        count0 = bn.num_batches_tracked.clone() if bn is not None and G > 1 else None
         for g in range(G):
             xg = x[:, g * cin:(g + 1) * cin].contiguous()
             w = conv.weight[g * cout:(g + 1) * cout]
             b = conv.bias[g * cout:(g + 1) * cout] if conv.bias is not None else None
             if bn is not None:
                 sl = slice(g * cout, (g + 1) * cout)
-                count = bn.num_batches_tracked if g == 0 else bn.num_batches_tracked.clone()
+                count = bn.num_batches_tracked if g == G - 1 else count0.clone()   # the module's counter moves once, last
                 outs.append(BF.ConvBNActFn.apply(
                     xg, w, b, bn.weight[sl], bn.bias[sl], bn.running_mean[sl], bn.running_var[sl], count,
                     self.training, plan["dilation"], code, leak, fused_residual, bn.momentum, bn.eps))
@@ -471,7 +474,11 @@ class ChannelMerger(nn.Module):
             # pair that occurs in the batch (torch.unique: one small host round trip, off the hot path); autograd
             # scatters the per-pair head gradients back into the [n_subjects, chout, pos_dim] parameter
             n_subjects = self.heads.shape[0]
-            subjects = batch.subject_index.to(meg.device, torch.int64)
+            # range-checked on the device like SubjectLayers (the reference's `heads.gather` raises, common.py:349): an
+            # index >= n_subjects sets the index-error flag (raised at the Solver's next check) and is clamped to 0
+            # instead of silently aliasing another (layout, subject) pair
+            subjects = BF.H.index_i32(batch.subject_index.to(meg.device, torch.int64).contiguous(),
+                                      n_subjects).to(torch.int64)
             pairs, inverse = torch.unique(layout_index * n_subjects + subjects, return_inverse=True)
             return BF.ChannelMergerFn.apply(meg, self.heads[pairs % n_subjects].contiguous(),
                                             positions_u[pairs // n_subjects].contiguous(), inverse.contiguous(),

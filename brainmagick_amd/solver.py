@@ -26,8 +26,14 @@ class Solver:
                  offset_meg_ms: float = 0., sample_rate: float = 120., negatives: str = "local",
                  lr: float = 3e-4, betas=(0.9, 0.999), scale_reject=None,
                  feature_model: tp.Optional[torch.nn.Module] = None, check_finite: bool = True,
-                 n_negatives: tp.Optional[int] = None, negative_pool_size: tp.Optional[int] = None):
+                 n_negatives: tp.Optional[int] = None, negative_pool_size: tp.Optional[int] = None,
+                 batch_size: tp.Optional[int] = None):
+        """``batch_size``: the configured per-rank batch size (`optim.batch_size` / world size, bm/train.py:37-39).
+        Only whole-node negatives next to per-rank rejection need it: it is the block every rank contributes to the
+        candidate all-gather.  Without it the block is the local batch's length and is verified over the ranks each
+        step (one tiny all-reduce + read-back; that mode reads back its rejection count anyway)."""
         assert negatives in ("local", "node")
+        self.batch_size = batch_size
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None and torch.cuda.is_available():
             self.device = torch.device("cuda", torch.cuda.current_device())      # comparable with tensor.device
@@ -159,7 +165,13 @@ class Solver:
         features = features.contiguous()
         if self._gather is not None and self.feature_model is None:
             # candidates do not depend on the model: start the xGMI all-gather before the encoder
-            self._gather.start(features, block_rows=nominal if self._ragged_node else None)
+            if self._ragged_node:
+                if self.batch_size is not None and nominal > self.batch_size:
+                    raise ValueError(f"batch of {nominal} segments exceeds Solver(batch_size={self.batch_size})")
+                self._gather.start(features, block_rows=self.batch_size or nominal,
+                                   verify_block=self.batch_size is None)
+            else:
+                self._gather.start(features)
         return batch, meg.contiguous(), features, features_mask, reject_mask
 
     def prefetch(self, next_batch) -> None:
@@ -300,6 +312,9 @@ class Solver:
             m.train(True)
         self.loss.train(True)
         self._substituted = False
+        # what the asserts of bm/solver.py:258-260 must leave untouched when they fire (the reference raises before it
+        # touches any state; here they are evaluated after the forward pass, so that state is put back: `_rollback`)
+        undo = self._snapshot()
         estimate, output, features_mask, _ = self._process_batch(batch, training=True, defer_flags=True)
         if estimate is None:
             # bm/solver.py:345-352: a fully rejected batch re-uses the last good one so that every
@@ -322,13 +337,52 @@ class Solver:
                 loss = loss + mod.training_penalty.to(loss.device)
         # the asserts of bm/solver.py:258-260 (this batch) and of the previous step: before anything is updated
         ticket, self._flag_ticket = self._flag_ticket, None
-        self._check_flags(ticket)
+        try:
+            self._check_flags(ticket)
+        except (AssertionError, IndexError):
+            self._rollback(undo)
+            raise
         self.optimizer.zero_grad(set_to_none=True)
         with self.optimizer.writing_grads():       # the weight-gradient kernels write straight into the flat bucket
             loss.backward()
         self.optimizer.collect_grads()      # one multi-tensor copy instead of an accumulate-add per parameter
         distrib.sharded_step(self.optimizer, self._buffers)
         return loss.detach()
+
+    def _snapshot(self):
+        """What a deferred assert must be able to put back (``_rollback``): references to the last good batch and the
+        negatives pool, the state of the pool's generator, and ONE small device copy of the flat BatchNorm buffer
+        bucket (6 400 floats for the paper model)."""
+        if not self.check_finite:
+            return None
+        flat = self._buffers.flat
+        if flat is not None:
+            if getattr(self, "_buffers_undo", None) is None or self._buffers_undo.shape != flat.shape:
+                self._buffers_undo = torch.empty_like(flat)
+            self._buffers_undo.copy_(flat)
+        gen = self.negative_generator.get_state() if (self.n_negatives is not None and
+                                                      self.negative_generator is not None) else None
+        return self._last_batch, dict(self.negative_pool), gen
+
+    def _rollback(self, undo) -> None:
+        """A deferred assert fired after the forward pass of ``train_step``: restore what the reference, which asserts
+        before it touches anything (bm/solver.py:258-260), would not have touched -- the "last good batch" (a later
+        fully rejected batch must not re-train on the poisoned one), the negatives pool (it would keep the non-finite
+        candidates) and its generator, the BatchNorm running statistics and batch counters.  Gradients were not
+        computed and the optimizer has not stepped.  (Independently of this, ``bn_finalize`` leaves the running
+        statistics alone when the batch statistics are not finite -- a deliberate deviation from ``nn.BatchNorm1d``,
+        which would poison its running estimates for good; README "Deviations".)"""
+        if undo is None:
+            return
+        self._last_batch, self.negative_pool, gen = undo
+        if gen is not None:
+            self.negative_generator.set_state(gen)
+        if self._buffers.flat is not None:
+            self._buffers.flat.copy_(self._buffers_undo)
+        for model in self._all_models():
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.num_batches_tracked is not None:
+                    mod.num_batches_tracked.sub_(1)
 
     # -- checkpoint (bm/solver.py:64,115-117: flashy's commit writes the registered state on rank 0) --------
     def state_dict(self) -> dict:

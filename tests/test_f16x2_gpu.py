@@ -488,12 +488,17 @@ def test_parameters_are_packed_once_per_step(h2_mode, H):
         next(p for p in model.parameters() if p.dim() == 3 and p.shape[2] == 3).mul_(1.5)
     e2 = float(solver.eval_step(sb))
     assert H.pack_launches == n1 + 1 and e2 != e1
-    # ... and the batched packing gives the same numbers as per-conv packing
-    H._BATCH_PACK = False
+    # ... and the batched packing gives the same numbers as per-conv packing (the path non-leaf / frozen weights take:
+    # one bm_pack_weights_h2 launch per conv)
+    for p in model.parameters():
+        p.requires_grad_(False)
     try:
+        n2 = H.pack_launches
         e3 = float(solver.eval_step(sb))
+        assert H.pack_launches - n2 > 1, "frozen weights should have been packed conv by conv"
     finally:
-        H._BATCH_PACK = True
+        for p in model.parameters():
+            p.requires_grad_(True)
     assert e3 == e2, (e2, e3)
     assert all(math.isfinite(v) for v in losses)
 

@@ -679,3 +679,136 @@ def test_header_prototypes_match_the_definitions():
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{ROOT / 'include'}", str(tu)],
                            capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[:2000]
+
+
+# -- the reference Solver's contract, read from its source ----------------------------------------------------------
+REFERENCE_BM = Path("/root/reference/bm")
+
+# function -> {root expression (as source) -> role}: which local names / attributes of the reference's own code hold
+# the objects that brainmagick_amd replaces
+_CONTRACT_ROOTS = {
+    ("solver.py", "Solver._process_batch"): {"self.model": "model", "self.feature_model": "feature_model",
+                                             "self.scale_reject": "scale_reject", "batch": "batch"},
+    ("solver.py", "Solver._run_one_epoch"): {"self.model": "model", "self.loss": "loss", "self.optimizer": "optimizer",
+                                             "self.all_models": "module_list", "batch": "batch"},
+    ("solver.py", "Solver._create_loss"): {"loss": "loss", "self.optimizer": "optimizer", "ClipLoss": "loss_class"},
+    ("solver.py", "Solver.train"): {"self.scale_reject": "scale_reject"},
+    ("solver.py", "Solver.predict"): {"SegmentBatch": "batch_class"},
+    ("wer.py", "get_wer"): {"solver.model": "model", "solver.loss": "loss", "clip": "loss", "batch": "batch"},
+}
+
+
+def _reference_touches():
+    """{role: {attribute or "__call__": [(n positional, (keyword names))]}} -- every attribute the reference's hot
+    loop reads on, and every call it makes to, the objects in _CONTRACT_ROOTS, by walking the AST of the reference
+    sources (nothing is imported: flashy / dora / julius are absent from this image)."""
+    import ast
+    touches = {}
+
+    def note(role, name, call=None):
+        calls = touches.setdefault(role, {}).setdefault(name, [])
+        if call is not None and call not in calls:
+            calls.append(call)
+
+    trees = {}
+    for (fname, qual), roots in _CONTRACT_ROOTS.items():
+        tree = trees.setdefault(fname, ast.parse((REFERENCE_BM / fname).read_text()))
+        node = tree
+        for part in qual.split("."):
+            node = next(n for n in ast.walk(node) if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name == part)
+        for n in ast.walk(node):
+            if isinstance(n, ast.Call):
+                src = ast.unparse(n.func)
+                sig = (len(n.args), tuple(sorted(k.arg for k in n.keywords if k.arg)),
+                       any(k.arg is None for k in n.keywords))
+                if src in roots:
+                    note(roots[src], "__call__", sig)
+                elif isinstance(n.func, ast.Attribute) and ast.unparse(n.func.value) in roots:
+                    note(roots[ast.unparse(n.func.value)], n.func.attr, sig)
+            elif isinstance(n, ast.Attribute) and ast.unparse(n.value) in roots:
+                note(roots[ast.unparse(n.value)], n.attr)
+            elif isinstance(n, ast.Call) is False and isinstance(n, ast.Name) and False:
+                pass
+        # len(batch...) / `if self.scale_reject:` style uses
+        for n in ast.walk(node):
+            if isinstance(n, ast.Call) and ast.unparse(n.func) == "len" and n.args and ast.unparse(n.args[0]) in roots:
+                note(roots[ast.unparse(n.args[0])], "__len__")
+    return touches
+
+
+@pytest.mark.skipif(not REFERENCE_BM.exists(), reason="needs the reference checkout (build container only)")
+def test_reference_solver_contract_is_met_by_the_replacement_classes():
+    """INTEGRATION.md section 4 says the maintainer changes imports and one factory line and `bm/solver.py` /
+    `bm/wer.py` stay as they are.  flashy / dora are absent, so the reference Solver cannot RUN here; this is the next
+    best thing: every attribute `bm/solver.py:230-321, 343-394` and `bm/wer.py:21-121` touch on the model, the loss,
+    the optimizer, the batch and ScaleReject is looked up on the replacement classes, and every call is bound against
+    the replacement's signature with the reference's own argument count and keyword names."""
+    import inspect
+    from brainmagick_amd import synthetic
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.losses import ClipLoss
+    from brainmagick_amd.norm import ScaleReject
+    from brainmagick_amd.optim import FlatAdam
+    touches = _reference_touches()
+    # the walk found the calls the hot loop is made of (a reference that moved would fail here, not pass vacuously)
+    assert (2, (), False) in touches["model"]["__call__"]                     # self.model(inputs, batch)
+    assert "modules" in touches["model"] and "eval" in touches["model"]
+    assert (3, (), False) in touches["loss"]["__call__"]                      # self.loss(estimate, output, features_mask)
+    assert {"train", "eval", "parameters", "get_probabilities", "to"} <= set(touches["loss"]) | {"to"}
+    assert {"zero_grad", "step", "add_param_group"} <= set(touches["optimizer"])
+    assert {"to", "meg", "features", "features_mask", "replace"} <= set(touches["batch"])
+    assert "rejection_rate" in touches["scale_reject"] and "__call__" in touches["scale_reject"]
+    assert "train" in touches["module_list"] and "state_dict" in touches["module_list"]
+
+    batch = synthetic.make_batch(3, 6, 16, 4, 2, seed=0)
+    model = SimpleConv(in_channels={"meg": 6}, out_channels=4, hidden={"meg": 8}, n_subjects=2, depth=2,
+                       merger=False, subject_layers=False)
+    loss = ClipLoss()
+    # (FlatAdam and ScaleReject as classes: their instances need a GPU / a fitted scaler)
+    from brainmagick_amd.models import DeepMel
+    providers = {"model": model, "feature_model": DeepMel(4, 8, 2, 4, kernel=3, stride=1), "loss": loss, "optimizer": FlatAdam, "batch": batch,
+                 "scale_reject": ScaleReject, "module_list": torch.nn.ModuleList([model]),
+                 "loss_class": ClipLoss, "batch_class": type(batch)}
+
+    def bind(fn, sig, what):
+        npos, kws, has_star = sig
+        try:
+            inspect.signature(fn).bind(*([None] * npos), **{k: None for k in kws})
+        except TypeError as exc:
+            if has_star and not kws:
+                return                      # `ClipLoss(**kw, ...)`: the keyword names are configuration, checked below
+            raise AssertionError(f"{what}: the reference calls it with {npos} positional + {kws}: {exc}")
+
+    # the wav2vec2 branch of bm/solver.py:304-316 (`feature_model.device`, `feature_model(output, output_dim=...)`)
+    # belongs to bm/features' fine-tuned wav2vec2 model, outside SURVEY section 8; the DeepMel branch (:318) is the one
+    # the replacement serves
+    touches["feature_model"].pop("device", None)
+    touches["feature_model"]["__call__"] = [c for c in touches["feature_model"]["__call__"] if "output_dim" not in c[1]]
+    assert (1, (), False) in touches["feature_model"]["__call__"]
+    for role, attrs in touches.items():
+        obj = providers[role]
+        for name, calls in attrs.items():
+            if name == "__call__":
+                target = obj if inspect.isclass(obj) else (obj.forward if isinstance(obj, torch.nn.Module) else obj.__call__)
+                if role == "scale_reject":
+                    target = ScaleReject.__call__
+                    calls = [(c[0] + 1, c[1], c[2]) for c in calls]           # unbound: + self
+                for sig in calls:
+                    bind(target, sig, f"{role}(...)")
+                continue
+            assert hasattr(obj, name), f"the reference touches `{role}.{name}`; {type(obj).__name__} has no such attribute"
+            for sig in calls:
+                member = getattr(obj, name)
+                if inspect.isclass(obj) and inspect.isfunction(member):
+                    sig = (sig[0] + 1, sig[1], sig[2])                        # unbound: + self
+                if callable(member) and not isinstance(member, torch.Tensor):
+                    bind(member, sig, f"{role}.{name}(...)")
+    # `ClipLoss(**args.clip, dset_args=args.dset)` (bm/solver.py:85-88): every key of conf/config.yaml's `clip:` block
+    # minus the two the Solver pops must be a constructor argument
+    import yaml
+    clip_cfg = yaml.safe_load((REFERENCE_BM / "conf" / "config.yaml").read_text())["clip"]
+    kw = {k: v for k, v in clip_cfg.items() if k not in ("save_best", "sync_grad")}
+    inspect.signature(ClipLoss).bind(**kw, dset_args=None)
+    # SegmentBatch(meg, features, mask, subjects, recordings) positionally (bm/solver.py `predict`)
+    for sig in touches["batch_class"]["__call__"]:
+        bind(type(batch), sig, "SegmentBatch(...)")

@@ -3,6 +3,7 @@
 synthetic batches.  fp32 tolerances: forward rel-L2 <= 1e-5, gradients <= 1e-4,
 step-0 loss |delta| <= 1e-4."""
 import copy
+import os
 
 import pytest
 import torch
@@ -265,6 +266,46 @@ def test_full_size_step_against_oracle(cfg_name, B):
             worst = max(worst, (rel_l2(p.grad, grads_ref[k]), k))
     print(f"full-size {cfg_name} B={B}: loss {float(loss):.7f} vs oracle {float(loss_ref):.7f}, "
           f"worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
+
+
+def test_full_size_horizon_20_steps_against_oracle(steps: int = 20):
+    """The 9 M-parameter paper model at cfg2's FULL size (batch 256, T = 360) for 20 consecutive Adam steps on a
+    stream of 4 distinct batches, side by side with the CPU oracle from the same initial state: the loss of EVERY step
+    within LOSS_TOL (1e-4 absolute), i.e. drift that only shows at depth 10 with BatchNorm over 92 160 samples would
+    show here.  After the last step: BatchNorm running statistics and the parameters (Adam's +-lr noise moves on
+    round-off-level gradients excepted, see adam_params_close).  ~6 s of host time per oracle step on 32 threads."""
+    from brainmagick_amd.solver import Solver
+    c = synthetic.CONFIGS["cfg2"]
+    batches = [synthetic.make_config_batch("cfg2", seed=2036 + i, batch=256) for i in range(4)]
+    model = _paper_model(c["C"], c["F"], c["S"], seed=2036)
+    oracle = O.OracleModel(copy.deepcopy(model.state_dict()), O.CLIP_CONV_CFG, 320, c["F"])
+    ban = torch.tensor([0.4, 0.6])
+    model.merger.ban_center_override = ban
+    solver = Solver(model)
+    dev_batches = [sb.to(solver.device) for sb in batches]
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or prev))
+    gaps, noise, grads_ref, gscale = [], set(), None, 1.0
+    try:
+        for step in range(steps):
+            sb = batches[step % 4]
+            loss = solver.train_step(dev_batches[step % 4])
+            loss_ref, _, grads_ref = oracle.train_step(sb.meg, sb.positions(), sb.subject_index, sb.features, ban)
+            gaps.append(abs(float(loss) - float(loss_ref)))
+            assert gaps[-1] < LOSS_TOL, (step, float(loss), float(loss_ref), gaps)
+            gscale = max(v.double().norm().item() for v in grads_ref.values())
+            noise |= {k for k, v in grads_ref.items() if is_noise_grad(v, gscale)}
+    finally:
+        torch.set_num_threads(prev)
+    print(f"full-size horizon: {steps} steps, largest loss gap {max(gaps):.2e} (last loss {float(loss):.6f})")
+    for k, v in model.state_dict().items():
+        if k in noise or not v.is_floating_point():
+            continue
+        if k in grads_ref:
+            ok, info = adam_params_close(v, oracle.sd[k], steps, grads_ref[k], gscale)
+            assert ok, (k, info)
+        else:
+            assert running_stat_close(v, oracle.sd[k], steps), k
 
 
 def test_offset_meg_ms_slicing_like_the_reference():
@@ -1054,6 +1095,42 @@ def test_rejected_batch_reuses_last_and_nonfinite_asserts():
     with pytest.raises(AssertionError):
         fresh.train_step(inf)
     assert torch.isfinite(fresh.train_step(good))      # the flag does not stick
+
+
+def test_a_failed_assert_leaves_no_trace_in_the_solver_state():
+    """The asserts of bm/solver.py:258-260 fire BEFORE the reference touches anything.  Here they are evaluated after
+    the forward pass (asynchronous flag read), so what the forward pass touched is put back: the "last good batch",
+    the negatives pool, the BatchNorm batch counters; the running statistics were never updated (bn_finalize skips a
+    non-finite batch); a caller that catches the AssertionError continues exactly as if the batch had not existed."""
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
+
+    def run(poison):
+        model, _ = _small_model(merger_dropout=0.0)      # (no draw on the device generator: the runs stay comparable)
+        solver = Solver(model, n_negatives=6, scale_reject=ScaleReject(
+            DeviceBatchScaler(torch.zeros(1, 20), torch.ones(1, 20)), limit=20, clip=False))
+        solver.negative_generator = torch.Generator().manual_seed(3)
+        good = [synthetic.make_batch(4, 20, 48, 10, 3, seed=10 + i) for i in range(3)]
+        losses = [float(solver.train_step(good[0]))]
+        if poison:
+            nan = synthetic.make_batch(4, 20, 48, 10, 3, seed=99)
+            nan.features[1, 2, 3] = float("nan")
+            with pytest.raises(AssertionError):
+                solver.train_step(nan)
+            assert solver._last_batch is good[0]
+            assert not any(bool(torch.isnan(b).any()) for b in solver.negative_pool.values() if b is not None)
+        # a fully rejected batch now re-trains on the last GOOD batch
+        rejected = synthetic.make_batch(4, 20, 48, 10, 3, seed=5)
+        rejected.meg = rejected.meg * 1e4
+        losses.append(float(solver.train_step(rejected)))
+        losses.append(float(solver.train_step(good[1])))
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}
+
+    clean_losses, clean_sd = run(False)
+    losses, sd = run(True)
+    assert losses == clean_losses, (losses, clean_losses)
+    for k, v in sd.items():
+        assert torch.equal(v, clean_sd[k]), k            # incl. num_batches_tracked and the running statistics
 
 
 def test_prefetch_is_by_identity_and_can_be_abandoned():
