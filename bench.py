@@ -20,11 +20,17 @@ reduce-scatter + all-gather on the flat bucket, on RCCL behind the C-ABI (bm_com
 Rank 0 prints ONE JSON line with the driver's contract plus
   ``roofline``       dominant kernel, timed with HIP events on the launch stream in a second, untimed
                      pass over the same batches right after the timed region (no event records inside
-                     the timed region);
-  ``roofline_clip``  the ClipLoss contraction (bm/losses.py:91-95) the same way, for cfg2 and cfg3 shapes;
+                     the timed region); ``traffic`` = HBM bytes per launch MEASURED IN THIS RUN by two
+                     ``rocprofv3 --pmc`` children (FETCH_SIZE, WRITE_SIZE) over a 5-step child of this script
+                     while this process leaves the GPU alone (``traffic_source`` "live"; the committed
+                     ``profiles/*pmc_summary.json`` is the fallback: "committed:<file>");
+  ``roofline_clip``  the ClipLoss contraction (bm/losses.py:91-95) the same way, for cfg2 - cfg4 shapes;
+  ``comm_ms``        (N > 1) HIP-event time per step of every collective, per phase;
   ``cpu_baseline``   the CPU oracle (torch-CPU restatement of the reference path, kind "port": the
-                     reference modules themselves need /root/reference, absent on the GPU box) on cfg1
-                     (batch 16) with 1 thread (what bm/train.py:182 configures) and with all host cores.
+                     reference modules themselves need /root/reference, absent on the GPU box; timed beside
+                     the live reference in the build container: profiles/r5_port_vs_reference.json) on the
+                     configuration of ``value`` itself (cfg2, batch 256, 32 threads), with cfg1 (batch 16,
+                     1 thread = what bm/train.py:182 configures, and 32 threads) as a sub-block.
 """
 import argparse
 import gc
@@ -107,6 +113,90 @@ def pmc_traffic(kernel_label: str):
     return None, files[-1].name, None
 
 
+def _pmc_counter_csv(counter, args, timeout):
+    """One `rocprofv3 --pmc <counter> --kernel-trace` pass over a 2-step child of this script (cwd /tmp, TMPDIR=/tmp,
+    counters in their own run: MI355X_MICROARCH.md, rocprofv3 section).  Returns {kernel: [launches, sum]} or None."""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="bm_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "bench", "--",
+           sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--workload", args.workload,
+           "--batch", str(args.batch), "--dtype", args.dtype, "--no-cpu-baseline", "--accuracy-steps", "0", "--no-exact",
+           "--no-clip", "--no-side-blocks", "--no-pmc"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BM_FORCE_DISTRIBUTED"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+        return read_counter_csvs(tmp, counter)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def read_counter_csvs(root, counter):
+    """{kernel name without its argument list: [dispatches, sum of the counter]} over every
+    `*counter_collection.csv` rocprofv3 wrote under `root` (one row per dispatch and counter)."""
+    import csv
+    acc = {}
+    for f in Path(root).rglob("*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                a = acc.setdefault(k, [0, 0.0])
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    return acc or None
+
+
+def traffic_from_counters(fetch, write, kernel_label, child_steps):
+    """(bytes per launch of the dominant kernel, its dispatches, HBM bytes per step over all kernels, top-12 table)
+    from the two counter passes; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section)."""
+    prefix = kernel_label.rstrip(">").replace(" ", "")
+    per_launch = launches = None
+    total = 0.0
+    table = {}
+    for k, (n, f) in fetch.items():
+        w = write.get(k)
+        if w is None:
+            continue
+        b = (2.0 * f / n + w[1] / w[0]) * 1024.0
+        total += b * n
+        table[k] = {"launches_per_step": n / child_steps, "hbm_bytes_per_launch": b}
+        if k.replace(" ", "").startswith(prefix):
+            per_launch, launches = b, n
+    top = dict(sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"])[:12])
+    return per_launch, launches, total / child_steps, top
+
+
+def live_pmc_traffic(kernel_label, args, child_steps=5, timeout=240):
+    """HBM traffic measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one
+    pass) over a short child of this very script, while this process keeps the GPU idle.  Corrections as the guide
+    prescribes: both counters are in KiB and FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950
+    -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns None when rocprofv3 is missing, this process is
+    itself being profiled, or a pass fails -- the caller then falls back to the committed summary."""
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    t0 = time.perf_counter()
+    fetch = _pmc_counter_csv("FETCH_SIZE", args, timeout)
+    write = _pmc_counter_csv("WRITE_SIZE", args, timeout) if fetch else None
+    if not fetch or not write:
+        return None
+    per_launch, launches, step_bytes, top = traffic_from_counters(fetch, write, kernel_label, child_steps)
+    return {"hbm_bytes_per_launch": per_launch, "launches_counted": launches, "step_hbm_bytes": step_bytes,
+            "child_steps": child_steps, "seconds": time.perf_counter() - t0, "per_kernel": top,
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a child "
+                   "`bench.py --steps 2 --warmup 1` of the same workload (1 warm-up + 2 timed + 2 event-pass steps = "
+                   "5 steps; the child's set-up launches are counted into step_hbm_bytes: < 1 %); "
+                   "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md"}
+
+
 def cpu_baseline(seconds_budget=14.0, full_batch=True):
     """The CPU oracle (port of the reference path) on cfg1 = BASELINE.json configs[0] (fake-study shaped,
     batch 16), timed with 1 thread (bm/train.py:182) and with all host cores, bounded samples."""
@@ -164,12 +254,34 @@ def cpu_baseline(seconds_budget=14.0, full_batch=True):
             cfg2 = {"error": repr(exc)}
     torch.set_num_threads(prev)
     best = max(out.values(), key=lambda r: r["value"])
-    return dict(value=best["value"], unit="segments/s", cores=best["cores"], kind="port", cfg2_b256=cfg2,
-                sample=f"cfg1 (C=273 T=360 F=120, batch {B}), clip_conv model, whole training step "
-                       f"(forward + ClipLoss + backward + Adam), torch CPU fp32, median of "
-                       f"{best['steps_timed']} steps after 1 warm-up; CPU oracle = restatement of the reference "
-                       "path (the reference modules need /root/reference, absent on the GPU box)",
-                one_thread=out["one_thread"], all_cores=out["all_cores"], host_cores=ncores)
+    cfg1 = dict(value=best["value"], unit="segments/s", cores=best["cores"],
+                sample=f"cfg1 = BASELINE configs[0] (C=273 T=360 F=120, batch {B}), clip_conv model, whole training "
+                       f"step, torch CPU fp32, median of {best['steps_timed']} steps after 1 warm-up",
+                one_thread=out["one_thread"], all_cores=out["all_cores"])
+    ref_file = ROOT / "profiles" / "r5_port_vs_reference.json"
+    backing = None
+    if ref_file.exists():
+        try:
+            backing = json.loads(ref_file.read_text())
+            sub = backing.get("cfg2_b32") or {}
+            backing = {k: backing[k] for k in ("port_over_reference", "reference_seg_per_s", "port_seg_per_s",
+                                               "threads", "config", "where", "max_abs_loss_gap") if k in backing}
+            backing["cfg2_shapes_batch32"] = {k: sub[k] for k in ("port_over_reference", "reference_seg_per_s",
+                                                                  "port_seg_per_s", "max_abs_loss_gap") if k in sub}
+            backing["file"] = "profiles/" + ref_file.name
+        except Exception:
+            backing = None
+    note = ("CPU oracle = torch-CPU restatement of the reference path (kind \"port\": the reference modules need "
+            "/root/reference, absent on the GPU box); `port_vs_reference` = the same step timed on the LIVE reference "
+            "modules beside the port in the build container")
+    if cfg2 and "value" in cfg2:
+        # the configuration of `value` itself: like-for-like with the GPU number of this line
+        return dict(value=cfg2["value"], unit="segments/s", cores=cfg2["cores"], kind="port", sample=cfg2["sample"],
+                    step_s=cfg2["step_s"], steps_timed=cfg2["steps_timed"], cfg1_b16=cfg1, host_cores=ncores,
+                    port_vs_reference=backing, note=note)
+    return dict(value=cfg1["value"], unit="segments/s", cores=cfg1["cores"], kind="port",
+                sample=cfg1["sample"] + " (the cfg2 batch-256 sample failed or was disabled: " + repr(cfg2) + ")",
+                cfg1_b16=cfg1, cfg2_b256=cfg2, host_cores=ncores, port_vs_reference=backing, note=note)
 
 
 def retrieval_block(workload, B, steps, dev, n_train=16, n_held=4, noise=3.4):
@@ -507,6 +619,8 @@ def main():
     ap.add_argument("--no-side-blocks", action="store_true",
                     help="skip the sustained / single-stream / pcie-inclusive / retrieval-roofline blocks (A/B and "
                          "profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not spawn the rocprofv3 --pmc children that measure `roofline.traffic` in this run")
     ap.add_argument("--sustained-steps", type=int, default=200)
     ap.add_argument("--dtype", default=hip_ops.DEFAULT_COMPUTE_DTYPE, choices=sorted(hip_ops.COMPUTE_DTYPES),
                     help="compute mode of the contractions; every fp32-class mode (f16x2, f32x3, f32) is held to the "
@@ -574,8 +688,15 @@ def main():
     # second pass over the same stream with per-launch HIP events (NOT part of `value`)
     timer = hip_ops.KernelTimer()
     hip_ops.set_kernel_timer(timer)
+    comm_timer = distrib.CommTimer() if distrib.is_distributed() else None
+    distrib.set_comm_timer(comm_timer)
     event_pass_elapsed, _ = timed_steps(args.steps)
     hip_ops.set_kernel_timer(None)
+    distrib.set_comm_timer(None)
+    comm_ms = None
+    if comm_timer is not None:
+        torch.cuda.synchronize()
+        comm_ms = comm_timer.summary(args.steps)
     sustained = pcie = None
     if not args.no_side_blocks:
         # `value` comes from the driver's fixed --steps (0.3 s at 20 steps): the same loop over a longer window
@@ -638,6 +759,14 @@ def main():
     achieved = d["flops_per_launch"] / (d["avg_ms"] * 1e-3) / 1e12
     seg_flops = algorithmic_flops_per_segment(c["C"], c["T"], c["F"])
     traffic, traffic_src, traffic_avg_ms = pmc_traffic(dom)
+    # HBM traffic measured in THIS run (rocprofv3 children while this process leaves the GPU alone); they overlap with the
+    # CPU baseline, which keeps the GPU idle anyway.  Collected further down; the committed summary is the fallback.
+    pmc_box = {}
+    pmc_thread = None
+    if world == 1 and not args.no_pmc and not args.no_side_blocks and not zero_operands:
+        import threading
+        torch.cuda.synchronize()
+        pmc_thread = threading.Thread(target=lambda: pmc_box.update(live=live_pmc_traffic(dom, args)), daemon=True)
     # counters are collected in separate rocprofv3 runs and committed: a summary whose launch duration for this
     # kernel is off by more than 10 % from what has just been measured describes an older kernel
     traffic_stale = bool(traffic is not None and traffic_avg_ms and
@@ -659,7 +788,7 @@ def main():
                                f"F={c['F']} features, {c['S']} subjects, clip_conv SimpleConv "
                                f"({n_params} params) + ClipLoss + Adam",
                    "batch_per_gpu": B, "global_batch": world * B, "negatives": negatives,
-                   "parallelism": f"dp{world}", "comm": distrib.comm_kind(), "rccl_world": world,
+                   "parallelism": f"dp{world}", "comm": distrib.comm_kind(), "rccl_world": distrib.reported_world(),
                    "candidate_gather": ("prefetched one step ahead on a side stream" if prefetch else
                                         ("in front of the forward" if negatives == "node" else "none")),
                    "distinct_batches": stream.n, "final_loss": final_loss,
@@ -672,7 +801,7 @@ def main():
                                                 if args.dtype in ("f16x2", "f32x3") else None),
                      "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate passes)",
-                     "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                     "traffic_source": "committed:" + str(traffic_src), "traffic_stale": traffic_stale,
                      "traffic_summary_avg_launch_ms": traffic_avg_ms,
 
                      "avg_launch_ms": d["avg_ms"], "launches_per_step": d["launches"] / args.steps,
@@ -686,6 +815,11 @@ def main():
                      "hbm_roofline_frac_step": step_bytes / (PEAK_HBM_GBS * 1e9) / (elapsed / args.steps),
                      "algorithmic_bytes_per_step": step_bytes},
     }
+    # per-phase communication times of the event pass (HIP events on the stream each collective is enqueued on): what a
+    # first real multi-GPU run needs to explain itself.  `cand_gather` runs on the side stream under the backward pass;
+    # `gather_wait` is the part of it the compute stream actually waits for.
+    out["comm_ms"] = comm_ms
+    out["comm_world_reported"] = distrib.reported_world()
     out["dvfs_probe"] = dvfs
     out["sustained"] = sustained
     out["pcie_inclusive"] = pcie
@@ -714,10 +848,24 @@ def main():
             out["retrieval_parity"] = retrieval_parity_block(dev)
         except Exception as exc:
             out["retrieval_parity"] = {"error": repr(exc)}
+    if pmc_thread is not None:
+        torch.cuda.synchronize()          # nothing of this process runs on the GPU while the counters are read
+        pmc_thread.start()
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     else:
         out["cpu_baseline"] = None
+    if pmc_thread is not None:
+        pmc_thread.join(timeout=520)
+        live = pmc_box.get("live")
+        r = out["roofline"]
+        if live and live.get("hbm_bytes_per_launch"):
+            r["traffic_committed"] = {"traffic": r["traffic"], "source": r["traffic_source"], "stale": r["traffic_stale"]}
+            r["traffic"] = live["hbm_bytes_per_launch"]
+            r["traffic_source"] = "live"
+            r["traffic_stale"] = False
+            r["traffic_live"] = live
+            r["step_hbm_bytes"] = live["step_hbm_bytes"]
     distrib.barrier()
     flush_c_stdio()
     print(json.dumps(out), flush=True)

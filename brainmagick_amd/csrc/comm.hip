@@ -34,6 +34,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // optional
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;       // optional
 };
 
 RcclApi g_api;
@@ -60,6 +62,8 @@ int load_rccl() {
     BM_SYM(AllReduce, "ncclAllReduce")
     BM_SYM(GetErrorString, "ncclGetErrorString")
 #undef BM_SYM
+    g_api.CommCount = reinterpret_cast<decltype(g_api.CommCount)>(dlsym(h, "ncclCommCount"));
+    g_api.CommUserRank = reinterpret_cast<decltype(g_api.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     g_api.handle = h;
     return BM_OK;
 }
@@ -116,6 +120,20 @@ extern "C" int bm_comm_destroy(void* handle) {
 
 extern "C" int bm_comm_world(void* handle) { return handle ? static_cast<BmComm*>(handle)->world : 0; }
 extern "C" int bm_comm_rank(void* handle) { return handle ? static_cast<BmComm*>(handle)->rank : -1; }
+
+// The communicator's size / this process' rank AS RCCL REPORTS THEM (ncclCommCount / ncclCommUserRank): what a
+// multi-GPU run prints next to its numbers, so that "8 ranks" is the library's statement and not the launcher's.
+// -1 when the handle is null, the query fails or librccl lacks the symbol.
+extern "C" int bm_comm_reported_world(void* handle) {
+    if (!handle || !g_api.CommCount) return -1;
+    int n = -1;
+    return g_api.CommCount(static_cast<BmComm*>(handle)->comm, &n) == ncclSuccess ? n : -1;
+}
+extern "C" int bm_comm_reported_rank(void* handle) {
+    if (!handle || !g_api.CommUserRank) return -1;
+    int r = -1;
+    return g_api.CommUserRank(static_cast<BmComm*>(handle)->comm, &r) == ncclSuccess ? r : -1;
+}
 
 // recv[r * count .. (r + 1) * count) = send of rank r, for every rank (fp32).
 extern "C" int bm_comm_allgather(void* handle, const float* send, float* recv, long count, void* stream) {

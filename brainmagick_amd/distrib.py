@@ -99,6 +99,9 @@ class _TorchComm:
     def scalar_device(self):
         return "cuda" if self.backend == "nccl" else "cpu"
 
+    def reported_world(self) -> int:
+        return dist.get_world_size()
+
     def close(self):
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -280,6 +283,10 @@ class _RcclComm:
     def scalar_device(self):
         return "cuda"
 
+    def reported_world(self) -> int:
+        """ncclCommCount of the live communicator: the world size as RCCL itself reports it."""
+        return int(self._lib.bm_comm_reported_world(self._h))
+
     def close(self):
         if self._h:
             torch.cuda.synchronize()
@@ -292,6 +299,62 @@ _comm: tp.Optional[tp.Any] = None
 
 def comm():
     return _comm
+
+
+class CommTimer:
+    """Optional per-phase timing of the step's collectives with HIP events ON THE STREAM EACH ONE IS ENQUEUED ON
+    (``bench.py --gpus N`` installs one for its event pass, so that a first real multi-GPU run explains itself):
+
+      reduce_scatter   gradients, in place on the flat bucket          (compute stream)
+      adam_shard       fused Adam on the own shard                     (compute stream; not communication, for scale)
+      all_gather       updated parameters, in place                    (compute stream)
+      buffer_allreduce BatchNorm running statistics                    (compute stream)
+      cand_gather      candidate all-gather of the whole-node negatives (side stream, overlapped with the backward pass)
+      gather_wait      what the compute stream actually WAITS for that gather when ClipLoss needs it (the exposed part)
+    """
+
+    def __init__(self):
+        self.records: tp.List[tp.Tuple[str, torch.cuda.Event, torch.cuda.Event]] = []
+
+    @contextlib.contextmanager
+    def phase(self, name: str):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()                      # on the CURRENT stream of the caller's context
+        try:
+            yield
+        finally:
+            end.record()
+            self.records.append((name, start, end))
+
+    def summary(self, steps: int) -> tp.Dict[str, tp.Dict[str, float]]:
+        """phase -> {calls, ms_per_step, avg_ms}; call after a device synchronize."""
+        acc: tp.Dict[str, tp.List[float]] = {}
+        for name, start, end in self.records:
+            acc.setdefault(name, []).append(start.elapsed_time(end))
+        return {k: dict(calls=len(v), ms_per_step=sum(v) / max(steps, 1), avg_ms=sum(v) / len(v))
+                for k, v in acc.items()}
+
+
+_comm_timer: tp.Optional[CommTimer] = None
+
+
+def set_comm_timer(timer: tp.Optional[CommTimer]) -> None:
+    global _comm_timer
+    _comm_timer = timer
+
+
+def _phase(name: str):
+    return _comm_timer.phase(name) if (_comm_timer is not None and torch.cuda.is_available()) \
+        else contextlib.nullcontext()
+
+
+def reported_world() -> int:
+    """The communicator's size as the communication library reports it (ncclCommCount / torch.distributed)."""
+    c = _adopt_torch_group()
+    if c is None:
+        return 1
+    fn = getattr(c, "reported_world", None)
+    return int(fn()) if fn is not None else int(c.world)
 
 
 def comm_kind() -> str:
@@ -418,15 +481,21 @@ def sharded_step(optimizer, buffers: tp.Optional["BufferBucket"] = None, shard: 
     if shard is None:
         shard = _SHARD_DEFAULT
     if shard:
-        bounds = sync_flat_gradients(optimizer)
-        optimizer.step(shard=bounds, grad_scale=1.0 / world_size())
-        _comm.all_gather_shards(optimizer.flat_param)
+        with _phase("reduce_scatter"):
+            bounds = sync_flat_gradients(optimizer)
+        with _phase("adam_shard"):
+            optimizer.step(shard=bounds, grad_scale=1.0 / world_size())
+        with _phase("all_gather"):
+            _comm.all_gather_shards(optimizer.flat_param)
     else:
-        _comm.all_reduce(optimizer.flat_grad)
-        optimizer.step(grad_scale=1.0 / world_size())
+        with _phase("all_reduce"):
+            _comm.all_reduce(optimizer.flat_grad)
+        with _phase("adam_full"):
+            optimizer.step(grad_scale=1.0 / world_size())
     hip_ops_weights_changed()               # parameters were written through raw pointers: packed copies are stale
     if buffers is not None:
-        buffers.average()
+        with _phase("buffer_allreduce"):
+            buffers.average()
 
 
 class BufferBucket:
@@ -553,7 +622,8 @@ class CandidateGather:
                 _comm.all_gather(counts, torch.full((1,), float(n), device=candidates.device, dtype=torch.float32))
                 rows = torch.arange(self._B, device=candidates.device, dtype=torch.float32)
                 self._valid = (rows[None, :] < counts[:, None]).to(torch.float32).reshape(-1).contiguous()
-            _comm.all_gather(out, send)
+            with _phase("cand_gather"):
+                _comm.all_gather(out, send)
         if side is not None:
             candidates.record_stream(side)
             cur = torch.cuda.current_stream()
@@ -576,7 +646,8 @@ class CandidateGather:
         if not is_distributed():
             return out, 0, None
         if self.stream is not None and out.is_cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            with _phase("gather_wait"):
+                torch.cuda.current_stream().wait_stream(self.stream)
         return out, rank() * self._B, valid
 
 

@@ -281,6 +281,8 @@ int bm_comm_init(const void* id, int world, int rank, int device, void** handle)
 int bm_comm_destroy(void* handle);
 int bm_comm_world(void* handle);
 int bm_comm_rank(void* handle);
+int bm_comm_reported_world(void* handle);                 /* ncclCommCount: the size RCCL itself reports (-1: unknown) */
+int bm_comm_reported_rank(void* handle);                  /* ncclCommUserRank */
 int bm_comm_allgather(void* handle, const float* send, float* recv, long count, void* stream);
 int bm_comm_reduce_scatter(void* handle, const float* send, float* recv, long count, void* stream);
 int bm_comm_allreduce(void* handle, const float* send, float* recv, long count, int op, void* stream);
