@@ -343,6 +343,174 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE-PASS BatchNorm backward (round 5).  The two-pass form above reads `dout` and `y` twice (236 + 236 MB per 320-channel
+// layer at B = 256) because dy needs the channel's sums of dz and dz * xhat before the first element can be written.
+// Here a workgroup keeps its slab of the channel IN REGISTERS between the two phases (dz and xhat of up to
+// 256 * FUSED_MAXIT float4 positions: 96 VGPRs), the `nsplit` workgroups of a channel exchange their partial sums
+// through memory inside the launch, and dout / y are read ONCE: 354 MB instead of 590 MB per layer, the GELU derivative
+// evaluated once per element instead of twice, one launch instead of two.
+//
+// In-launch hand-off (cdna_hip_programming.md section 6, Guideline 16, counter form): placement-independent.
+//   * a workgroup's (channel, split) comes from a TICKET drawn at its start (atomic counter), not from blockIdx: a
+//     ticket holder is running, so "every lower ticket has started" holds whatever order the dispatcher uses, and the
+//     splits of a channel are consecutive tickets.  A waiting workgroup only waits for tickets of its own channel; all
+//     lower channels are complete or running, so at most nsplit - 1 residency slots ever hold waiters whose partners have
+//     not started, and every other slot keeps turning over: no deadlock for any dispatch order or residency;
+//   * payload: thread 0 stores the two partial sums with agent-scope relaxed atomic stores (write-through, sc1), drains
+//     them (s_waitcnt vmcnt(0)), then arrives (agent-scope relaxed fetch_add); it polls the arrival counter relaxed with
+//     s_sleep and reads every split's sums with agent-scope relaxed atomic loads (sc1) -- no fence, no L2 write-back;
+//   * the spin is bounded: on a time-out the channel's dy is written as NaN (the step's loss turns non-finite and is
+//     refused by every caller) instead of hanging the GPU;
+//   * ticket and arrival words are zeroed by a hipMemsetAsync in front of every launch.
+// The sums are folded in split order by every workgroup alike: deterministic, bit-identical replicas.
+// ------------------------------------------------------------------------------------------------
+extern "C" int bm_bwd_nsplit(int B);
+#define FUSED_MAXIT 10
+#define FUSED_SPIN_LIMIT 60000u
+
+__device__ __forceinline__ void bm_store_agent_f64(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double bm_load_agent_f64(const double* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
+    const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    double* partial, unsigned* sync, int bn_train, float* __restrict__ dy, double* __restrict__ dy_partial,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int T, int nsplit, int act, float leak,
+    BmAmaxDst amax_ws, BmFastDiv div_tv) {
+    __shared__ double sh[4 * 2];
+    __shared__ float amax_sh[4];
+    __shared__ float k_sh[2];
+    __shared__ unsigned ticket_sh;
+    if (threadIdx.x == 0)
+        ticket_sh = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int c = (int)(ticket_sh / (unsigned)nsplit), split = (int)(ticket_sh - (unsigned)c * (unsigned)nsplit);
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const int TV = T / 4;
+    const unsigned nvec = (unsigned)(b1 - b0) * (unsigned)TV;            // <= 256 * FUSED_MAXIT (host check)
+    const float sc = scale[c], shf = shift[c], mu = mean[c], is = invstd[c];
+
+    // phase 1: the slab into registers, all loads in flight before the first use
+    float4 d[FUSED_MAXIT], v[FUSED_MAXIT];
+    unsigned off[FUSED_MAXIT];                                            // element offsets: B * C * T < 2^32 (host check)
+#pragma unroll
+    for (int it = 0; it < FUSED_MAXIT; ++it) {
+        const unsigned e = (unsigned)it * 256u + threadIdx.x;
+        const unsigned ee = e < nvec ? e : 0u;                           // past the slab: re-read position 0 (unused)
+        const unsigned bl = bm_div(ee, div_tv);
+        off[it] = ((unsigned)(b0 + (int)bl) * (unsigned)C + (unsigned)c) * (unsigned)T + (ee - bl * (unsigned)TV) * 4u;
+        d[it] = *reinterpret_cast<const float4*>(dout + off[it]);
+        v[it] = *reinterpret_cast<const float4*>(y + off[it]);
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < FUSED_MAXIT; ++it) {
+        const bool ok = (unsigned)it * 256u + threadIdx.x < nvec;
+        float* dd = reinterpret_cast<float*>(&d[it]);
+        float* vv = reinterpret_cast<float*>(&v[it]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dz = ok ? dd[i] * bm_act_grad(vv[i] * sc + shf, act, leak) : 0.f;
+            const float xh = (vv[i] - mu) * is;
+            dd[i] = dz;                                                   // d <- dz, v <- xhat: kept for phase 2
+            vv[i] = xh;
+            s0 += dz;
+            s1 += dz * xh;
+        }
+    }
+    double acc[2] = {(double)s0, (double)s1};
+    block_sum<2>(acc, sh);
+
+    // hand-off: publish this split's sums, wait for the channel's other splits, fold in split order
+    if (threadIdx.x == 0) {
+        double* mine = partial + ((long)c * nsplit + split) * 2;
+        bm_store_agent_f64(mine + 0, acc[0]);
+        bm_store_agent_f64(mine + 1, acc[1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* arrived = sync + 2 + c;
+        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        for (unsigned spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsplit;) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > FUSED_SPIN_LIMIT) { ok = false; break; }
+        }
+        double sdz = 0, sdzx = 0;
+        for (int k = 0; k < nsplit; ++k) {
+            sdz += bm_load_agent_f64(partial + ((long)c * nsplit + k) * 2 + 0);
+            sdzx += bm_load_agent_f64(partial + ((long)c * nsplit + k) * 2 + 1);
+        }
+        if (!ok) {
+            __hip_atomic_fetch_or(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sdz = sdzx = __builtin_nan("");
+        }
+        const double n = (double)B * T;
+        k_sh[0] = bn_train ? (float)(sdz / n) : (ok ? 0.f : __builtin_nanf(""));
+        k_sh[1] = bn_train ? (float)(sdzx / n) : 0.f;
+        if (split == 0) {
+            if (dgamma) dgamma[c] = (float)sdzx;
+            if (dbeta) dbeta[c] = (float)sdz;
+        }
+    }
+    __syncthreads();
+    const float k1 = k_sh[0], k2 = k_sh[1];
+
+    // phase 2: dy from the registers
+    float sdy = 0.f, amx = 0.f;
+#pragma unroll
+    for (int it = 0; it < FUSED_MAXIT; ++it) {
+        if ((unsigned)it * 256u + threadIdx.x < nvec) {
+            const float* dd = reinterpret_cast<const float*>(&d[it]);
+            const float* vv = reinterpret_cast<const float*>(&v[it]);
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g = bn_train ? sc * (dd[i] - k1 - vv[i] * k2) : sc * (dd[i] - k1);
+                o[i] = g;
+                sdy += g;
+                amx = fmaxf(amx, fabsf(g));
+            }
+            *reinterpret_cast<float4*>(dy + off[it]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    bm_publish_amax_at(amx, amax_ws, amax_sh, (unsigned)split * (unsigned)C + (unsigned)c);
+    double acc2[1] = {(double)sdy};
+    block_sum<1>(acc2, sh);
+    if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc2[0];
+}
+
+// A/B switch (default on; environment BM_BN_BWD_FUSED=0 or bm_act_bn_bwd_set_fused(0): the two-pass kernels)
+static int g_bn_bwd_fused = -1;
+extern "C" int bm_act_bn_bwd_set_fused(int on) {
+    const int prev = g_bn_bwd_fused;
+    g_bn_bwd_fused = on ? 1 : 0;
+    return prev;
+}
+
+// splits of the one-pass kernel: the smallest count whose per-split slab fits the registers; 0 = not covered
+static int fused_nsplit(int B, int C, int T) {
+    if (T % 4 != 0 || B <= 0 || (long)B * C * T >= 0xffffffffL) return 0;
+    if (g_bn_bwd_fused < 0) {
+        const char* e = getenv("BM_BN_BWD_FUSED");
+        g_bn_bwd_fused = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!g_bn_bwd_fused) return 0;
+    const long TV = T / 4, cap = 256L * FUSED_MAXIT;
+    if (TV > cap) return 0;
+    for (int n = bm_bwd_nsplit(B); n <= NSPLIT_MAX && n <= B; ++n) {
+        const long nb = ((long)B + n - 1) / n;          // the largest slab of `n` near-equal splits
+        if (nb * TV <= cap) return (long)C * n <= BM_AMAX_WS ? n : 0;
+    }
+    return 0;
+}
+extern "C" int bm_act_bn_bwd_fused_covers(int B, int C, int T) { return fused_nsplit(B, C, T) > 0; }
+
 // out[c] = sum_split partial[c][split]
 __global__ void finalize_channel_sums_kernel(const double* __restrict__ partial, float* __restrict__ out,
                                              int C, int nsplit) {
@@ -361,8 +529,10 @@ extern "C" int bm_bwd_nsplit(int B) { return B >= 64 ? 8 : (B >= 8 ? 4 : 1); }
 static int gelu_grad_code(int act) { return act == BM_ACT_GELU ? BM_ACT_GELU_FASTGRAD : act; }
 
 // workspace: doubles, (2*C*nsplit) for the reduce partials + (C*nsplit) for the dy sums.
+// (+ the ticket / time-out / per-channel arrival words of the one-pass kernel; sized for its largest split count)
 extern "C" long bm_act_bn_bwd_workspace_bytes(int B, int C) {
-    return (long)3 * C * bm_bwd_nsplit(B) * sizeof(double);
+    (void)B;
+    return (long)3 * C * NSPLIT_MAX * sizeof(double) + ((long)C + 8) * sizeof(unsigned);
 }
 
 extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* scale,
@@ -375,7 +545,9 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     BM_REQUIRE(!amax_out || (long)C * bm_bwd_nsplit(B) <= BM_AMAX_WS, "act_bn_bwd: too many channels for the amax workspace");
     BM_REQUIRE(!bn_train || (scale && shift && mean && invstd), "act_bn_bwd: train BN needs saved statistics");
     if ((long)B * C * T == 0) return BM_OK;
-    const int nsplit = bm_bwd_nsplit(B);
+    const bool reduce = bn_train || (scale && (dgamma || dbeta));
+    const int nfused = (reduce && scale && shift && mean && invstd) ? fused_nsplit(B, C, T) : 0;
+    const int nsplit = nfused ? nfused : bm_bwd_nsplit(B);
     if (workspace_bytes < bm_act_bn_bwd_workspace_bytes(B, C))
         return bm_set_error(BM_ERR_WORKSPACE, "act_bn_bwd: workspace too small (%ld < %ld)", workspace_bytes,
                             bm_act_bn_bwd_workspace_bytes(B, C));
@@ -384,9 +556,16 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     hipStream_t s = (hipStream_t)stream;
     const BmAmaxDst amax_dst = bm_amax_dst(amax_out, amax_ws);
     const dim3 grid(C, nsplit);
-    const bool reduce = bn_train || (scale && (dgamma || dbeta));
     act = gelu_grad_code(act);
-    if (T % 4 == 0) {
+    if (nfused) {
+        // one pass: the slab stays in registers between the sums and the apply (see bn_bwd_fused_kernel)
+        unsigned* sync = (unsigned*)((double*)workspace + (long)3 * C * NSPLIT_MAX);
+        hipError_t e = hipMemsetAsync(sync, 0, ((size_t)C + 2) * sizeof(unsigned), s);
+        if (e != hipSuccess) return bm_set_error((int)e, "act_bn_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3((unsigned)C * (unsigned)nsplit), dim3(256), 0, s, dout, y, scale,
+                           shift, mean, invstd, partial, sync, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit,
+                           act, leak, amax_dst, bm_fastdiv((unsigned)(T / 4)));
+    } else if (T % 4 == 0) {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,
                                invstd, partial, B, C, T, act, leak);

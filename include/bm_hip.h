@@ -185,6 +185,8 @@ int bm_affine_act_res(const float* y, const float* scale, const float* shift, co
                       void* stream);
 int bm_bwd_nsplit(int B);
 long bm_act_bn_bwd_workspace_bytes(int B, int C);
+int bm_act_bn_bwd_set_fused(int on);                      /* A/B switch of the one-pass form (default on); returns the previous setting (-1: unset) */
+int bm_act_bn_bwd_fused_covers(int B, int C, int T);      /* 1: train-mode BatchNorm backward runs as ONE pass (slab in registers) */
 int bm_act_bn_bwd(const float* dout, const float* y, const float* scale, const float* shift,
                   const float* mean, const float* invstd, int bn_train, float* dy, float* dgamma,
                   float* dbeta, float* dbias, void* workspace, long workspace_bytes, int B, int C,

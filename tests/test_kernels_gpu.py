@@ -141,6 +141,57 @@ def test_subject_layers_kernels(H):
     assert torch.count_nonzero(dW[1]) == 0
 
 
+@pytest.mark.parametrize("B,C,T", [(256, 320, 360),      # the production shape: 10 splits of <= 26 segments per channel
+                                   (173, 320, 360),      # ragged batch: splits of 17 / 18 segments
+                                   (37, 64, 192),        # one slab shorter than a workgroup's first trip
+                                   (6, 40, 360), (1, 8, 4), (64, 1500, 48)])
+def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
+    """bm_act_bn_bwd in train mode runs as ONE pass when T % 4 == 0 and a split's slab fits the registers
+    (bn_bwd_fused_kernel: the workgroups of a channel exchange their partial sums inside the launch): same results as
+    the two-pass kernels (to summation order), the fp64 formula, and bit-identical from run to run."""
+    from brainmagick_amd._lib import lib
+    assert lib().bm_act_bn_bwd_fused_covers(B, C, T) == 1
+    g = _gen(B + C + T)
+    y = torch.randn(B, C, T, generator=g) * 1.5 + 0.3
+    dout = torch.randn(B, C, T, generator=g)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    yd = y.double()
+    mean = yd.mean((0, 2))
+    invstd = 1.0 / torch.sqrt(yd.var((0, 2), unbiased=False) + 1e-5)
+    scale = gamma.double() * invstd
+    shift = beta.double() - mean * scale
+    args = [t.float().cuda() for t in (dout, y, scale, shift, mean, invstd)]
+
+    def run(fused):
+        prev = lib().bm_act_bn_bwd_set_fused(int(fused))
+        try:
+            dy, dgamma, dbeta, dbias = H.act_bn_bwd(*args, True, H.ACT_GELU, want_affine_grads=True)
+            amax, rows = H.amax(dy).clone(), H.row_amax_of(dy)
+            torch.cuda.synchronize()
+            return dy, dgamma, dbeta, dbias, amax, (rows.clone() if rows is not None else None)
+        finally:
+            lib().bm_act_bn_bwd_set_fused(1 if prev != 0 else 0)
+
+    one, again, two = run(True), run(True), run(False)
+    for a, b in zip(one, again):
+        assert a is None or torch.equal(a, b)                     # deterministic
+    # fp64 formula
+    z = yd * scale[None, :, None] + shift[None, :, None]
+    dz = dout.double() * (0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi))
+    xh = (yd - mean[None, :, None]) * invstd[None, :, None]
+    n = B * T
+    ref = scale[None, :, None] * (dz - dz.sum((0, 2), keepdim=True) / n - xh * (dz * xh).sum((0, 2), keepdim=True) / n)
+    for name, got in (("one-pass", one), ("two-pass", two)):
+        assert rel_l2(got[0], ref) < GRAD_TOL, name
+        assert rel_l2(got[1], (dz * xh).sum((0, 2))) < GRAD_TOL and rel_l2(got[2], dz.sum((0, 2))) < GRAD_TOL, name
+    assert rel_l2(one[0], two[0]) < 2e-6
+    assert float(one[4].max()) == float(one[0].abs().max())      # the published maximum is that of what was written
+    if one[5] is not None:
+        assert torch.equal(one[5].cpu(), one[0].abs().amax((0, 2)).cpu())
+    assert float(one[3].abs().max()) < 1e-2 * max(1.0, float(one[0].abs().max()))     # sum(dy) of a BN input is ~0
+
+
 @pytest.mark.parametrize("T", [360, 343])
 @pytest.mark.parametrize("act", ["gelu", "relu", "leaky"])
 def test_batchnorm_act_residual(H, T, act):
