@@ -346,62 +346,59 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // ------------------------------------------------------------------------------------------------
 // ONE-PASS BatchNorm backward (round 5).  The two-pass form above reads `dout` and `y` twice (236 + 236 MB per 320-channel
 // layer at B = 256) because dy needs the channel's sums of dz and dz * xhat before the first element can be written.
-// Here a workgroup keeps its slab of the channel IN REGISTERS between the two phases (dz and xhat of up to
-// 256 * FUSED_MAXIT float4 positions: 96 VGPRs), the `nsplit` workgroups of a channel exchange their partial sums
-// through memory inside the launch, and dout / y are read ONCE: 354 MB instead of 590 MB per layer, the GELU derivative
-// evaluated once per element instead of twice, one launch instead of two.
+// Here a workgroup keeps its slab of the channel IN REGISTERS between the two phases (dz and xhat of up to 256 * MAXIT
+// float4 positions), the `nsplit` workgroups of a channel exchange their partial sums through memory inside the launch,
+// and dout / y are read ONCE: 354 MB instead of 590 MB per layer, the GELU derivative evaluated once per element
+// instead of twice, one launch instead of two.
 //
-// In-launch hand-off (cdna_hip_programming.md section 6, Guideline 16, counter form): placement-independent.
-//   * a workgroup's (channel, split) comes from a TICKET drawn at its start (atomic counter), not from blockIdx: a
-//     ticket holder is running, so "every lower ticket has started" holds whatever order the dispatcher uses, and the
-//     splits of a channel are consecutive tickets.  A waiting workgroup only waits for tickets of its own channel; all
-//     lower channels are complete or running, so at most nsplit - 1 residency slots ever hold waiters whose partners have
-//     not started, and every other slot keeps turning over: no deadlock for any dispatch order or residency;
-//   * payload: thread 0 stores the two partial sums with agent-scope relaxed atomic stores (write-through, sc1), drains
-//     them (s_waitcnt vmcnt(0)), then arrives (agent-scope relaxed fetch_add); it polls the arrival counter relaxed with
-//     s_sleep and reads every split's sums with agent-scope relaxed atomic loads (sc1) -- no fence, no L2 write-back;
-//   * the spin is bounded: on a time-out the channel's dy is written as NaN (the step's loss turns non-finite and is
-//     refused by every caller) instead of hanging the GPU;
-//   * ticket and arrival words are zeroed by a hipMemsetAsync in front of every launch.
-// The sums are folded in split order by every workgroup alike: deterministic, bit-identical replicas.
+// In-launch hand-off, placement-independent (cdna_hip_programming.md section 6, Guideline 16, form R2 "the data is
+// the flag"): each partial sum is ONE naturally aligned 8-byte word, written with one agent-scope relaxed atomic store
+// (write-through, sc1) and read with agent-scope relaxed atomic loads; the words start out as a sentinel (all ones,
+// hipMemsetAsync in front of every launch; a sum that happens to have that NaN pattern is stored as the canonical NaN).
+// Wave 0 polls the channel's 2 * nsplit words (one lane each, s_sleep between polls) until none is the sentinel: no
+// fence, no counter, one memory round trip once the partners are done.
+// NO assumption about dispatch order or residency: the poll is bounded, and a workgroup whose partners have not
+// published in time COMPUTES THEIR SUMS ITSELF (re-reading their slabs with the very same per-thread summation order,
+// so the result is bit-identical) and goes on -- a partner that was never resident can therefore not dead-lock it, it
+// only makes it slower.  The sums are folded in split order by every workgroup alike: deterministic.
 // ------------------------------------------------------------------------------------------------
-extern "C" int bm_bwd_nsplit(int B);
-#define FUSED_MAXIT 10
-#define FUSED_SPIN_LIMIT 60000u
+#define FUSED_POLL_LIMIT 192u
+#define FUSED_SENTINEL 0xffffffffffffffffull
 
-__device__ __forceinline__ void bm_store_agent_f64(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double bm_load_agent_f64(const double* p) {
-    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+// dz and xhat of one element, and the running sums, in ONE place: the keeping pass and the fallback pass must round alike
+__device__ __forceinline__ void fused_elem(float dv, float yv, float sc, float shf, float mu, float is, int act,
+                                           float leak, bool ok, float& dz, float& xh, float& s0, float& s1) {
+    dz = ok ? dv * bm_act_grad(fmaf(yv, sc, shf), act, leak) : 0.f;
+    xh = (yv - mu) * is;
+    s0 += dz;
+    s1 = fmaf(dz, xh, s1);
 }
 
-__global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
+template <int MAXIT>
+__global__ __launch_bounds__(256, MAXIT > 6 ? 4 : 6) void bn_bwd_fused_kernel(
     const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    double* partial, unsigned* sync, int bn_train, float* __restrict__ dy, double* __restrict__ dy_partial,
+    unsigned long long* partial, int bn_train, float* __restrict__ dy, double* __restrict__ dy_partial,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int T, int nsplit, int act, float leak,
-    BmAmaxDst amax_ws, BmFastDiv div_tv) {
+    BmAmaxDst amax_ws, BmFastDiv div_tv, BmFastDiv div_ns, unsigned poll_limit) {
     __shared__ double sh[4 * 2];
     __shared__ float amax_sh[4];
     __shared__ float k_sh[2];
-    __shared__ unsigned ticket_sh;
-    if (threadIdx.x == 0)
-        ticket_sh = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int c = (int)(ticket_sh / (unsigned)nsplit), split = (int)(ticket_sh - (unsigned)c * (unsigned)nsplit);
-    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    __shared__ unsigned long long part_sh[2 * NSPLIT_MAX];
+    __shared__ unsigned missing_sh;
+    // consecutive workgroups = the splits of one channel (they start together under the observed dispatch order; the
+    // protocol does not depend on it)
+    const int c = (int)bm_div(blockIdx.x, div_ns), split = (int)(blockIdx.x - (unsigned)c * (unsigned)nsplit);
     const int TV = T / 4;
-    const unsigned nvec = (unsigned)(b1 - b0) * (unsigned)TV;            // <= 256 * FUSED_MAXIT (host check)
     const float sc = scale[c], shf = shift[c], mu = mean[c], is = invstd[c];
+    const int b0 = (int)((long)B * split / nsplit), b1 = (int)((long)B * (split + 1) / nsplit);
+    const unsigned nvec = (unsigned)(b1 - b0) * (unsigned)TV;            // <= 256 * MAXIT (host check)
 
     // phase 1: the slab into registers, all loads in flight before the first use
-    float4 d[FUSED_MAXIT], v[FUSED_MAXIT];
-    unsigned off[FUSED_MAXIT];                                            // element offsets: B * C * T < 2^32 (host check)
+    float4 d[MAXIT], v[MAXIT];
+    unsigned off[MAXIT];                                                 // element offsets: B * C * T < 2^32 (host check)
 #pragma unroll
-    for (int it = 0; it < FUSED_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const unsigned e = (unsigned)it * 256u + threadIdx.x;
         const unsigned ee = e < nvec ? e : 0u;                           // past the slab: re-read position 0 (unused)
         const unsigned bl = bm_div(ee, div_tv);
@@ -411,47 +408,90 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
     }
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int it = 0; it < FUSED_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const bool ok = (unsigned)it * 256u + threadIdx.x < nvec;
         float* dd = reinterpret_cast<float*>(&d[it]);
         float* vv = reinterpret_cast<float*>(&v[it]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dz = ok ? dd[i] * bm_act_grad(vv[i] * sc + shf, act, leak) : 0.f;
-            const float xh = (vv[i] - mu) * is;
-            dd[i] = dz;                                                   // d <- dz, v <- xhat: kept for phase 2
-            vv[i] = xh;
-            s0 += dz;
-            s1 += dz * xh;
-        }
+        for (int i = 0; i < 4; ++i) fused_elem(dd[i], vv[i], sc, shf, mu, is, act, leak, ok, dd[i], vv[i], s0, s1);
     }
     double acc[2] = {(double)s0, (double)s1};
     block_sum<2>(acc, sh);
 
-    // hand-off: publish this split's sums, wait for the channel's other splits, fold in split order
+    // publish this split's two sums (one 8-byte write-through word each)
+    unsigned long long* chan = partial + (long)c * nsplit * 2;
     if (threadIdx.x == 0) {
-        double* mine = partial + ((long)c * nsplit + split) * 2;
-        bm_store_agent_f64(mine + 0, acc[0]);
-        bm_store_agent_f64(mine + 1, acc[1]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned* arrived = sync + 2 + c;
-        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = true;
-        for (unsigned spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsplit;) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > FUSED_SPIN_LIMIT) { ok = false; break; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned long long bits = __builtin_bit_cast(unsigned long long, acc[j]);
+            if (bits == FUSED_SENTINEL) bits = 0x7ff8000000000000ull;
+            __hip_atomic_store(chan + split * 2 + j, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            part_sh[split * 2 + j] = bits;
         }
-        double sdz = 0, sdzx = 0;
+    }
+    // wave 0 polls the channel's words, one lane per word
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const bool mine = lane < 2 * nsplit && (lane >> 1) != split;
+        unsigned long long bits = 0;
+        bool ready = !mine;
+        for (unsigned polls = 0;; ++polls) {
+            if (!ready) {
+                bits = __hip_atomic_load(chan + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = bits != FUSED_SENTINEL;
+            }
+            if (__all(ready) || polls >= poll_limit) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        if (mine && ready) part_sh[lane] = bits;
+        const unsigned long long lagging = __ballot(!ready);             // bit 2k / 2k+1: split k has not published
+        if (lane == 0) {
+            unsigned m = 0;
+            for (int k = 0; k < nsplit; ++k) m |= ((lagging >> (2 * k)) & 3ull) ? (1u << k) : 0u;
+            missing_sh = m;
+        }
+    }
+    __syncthreads();
+    // partners that did not publish in time (never under a sane dispatcher): their sums, computed here, bit-identically
+    const unsigned missing = missing_sh;
+    if (missing) {
         for (int k = 0; k < nsplit; ++k) {
-            sdz += bm_load_agent_f64(partial + ((long)c * nsplit + k) * 2 + 0);
-            sdzx += bm_load_agent_f64(partial + ((long)c * nsplit + k) * 2 + 1);
+            if (!((missing >> k) & 1u)) continue;
+            const int kb0 = (int)((long)B * k / nsplit), kb1 = (int)((long)B * (k + 1) / nsplit);
+            const unsigned knvec = (unsigned)(kb1 - kb0) * (unsigned)TV;
+            float t0 = 0.f, t1 = 0.f;
+            for (int it = 0; it < MAXIT; ++it) {
+                const unsigned e = (unsigned)it * 256u + threadIdx.x;
+                const bool ok = e < knvec;
+                const unsigned ee = ok ? e : 0u;
+                const unsigned bl = bm_div(ee, div_tv);
+                const unsigned o = ((unsigned)(kb0 + (int)bl) * (unsigned)C + (unsigned)c) * (unsigned)T + (ee - bl * (unsigned)TV) * 4u;
+                const float4 dv = *reinterpret_cast<const float4*>(dout + o);
+                const float4 yv = *reinterpret_cast<const float4*>(y + o);
+                const float* dd = reinterpret_cast<const float*>(&dv);
+                const float* vv = reinterpret_cast<const float*>(&yv);
+                float dz, xh;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fused_elem(dd[i], vv[i], sc, shf, mu, is, act, leak, ok, dz, xh, t0, t1);
+            }
+            double a2[2] = {(double)t0, (double)t1};
+            __syncthreads();
+            block_sum<2>(a2, sh);
+            if (threadIdx.x == 0) {
+                part_sh[2 * k + 0] = __builtin_bit_cast(unsigned long long, a2[0]);
+                part_sh[2 * k + 1] = __builtin_bit_cast(unsigned long long, a2[1]);
+            }
         }
-        if (!ok) {
-            __hip_atomic_fetch_or(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sdz = sdzx = __builtin_nan("");
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double sdz = 0, sdzx = 0;
+        for (int k = 0; k < nsplit; ++k) {                               // split order: the same fold in every workgroup
+            sdz += __builtin_bit_cast(double, part_sh[2 * k + 0]);
+            sdzx += __builtin_bit_cast(double, part_sh[2 * k + 1]);
         }
         const double n = (double)B * T;
-        k_sh[0] = bn_train ? (float)(sdz / n) : (ok ? 0.f : __builtin_nanf(""));
+        k_sh[0] = bn_train ? (float)(sdz / n) : 0.f;
         k_sh[1] = bn_train ? (float)(sdzx / n) : 0.f;
         if (split == 0) {
             if (dgamma) dgamma[c] = (float)sdzx;
@@ -464,14 +504,14 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
     // phase 2: dy from the registers
     float sdy = 0.f, amx = 0.f;
 #pragma unroll
-    for (int it = 0; it < FUSED_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         if ((unsigned)it * 256u + threadIdx.x < nvec) {
             const float* dd = reinterpret_cast<const float*>(&d[it]);
             const float* vv = reinterpret_cast<const float*>(&v[it]);
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float g = bn_train ? sc * (dd[i] - k1 - vv[i] * k2) : sc * (dd[i] - k1);
+                const float g = sc * (dd[i] - k1 - vv[i] * k2);
                 o[i] = g;
                 sdy += g;
                 amx = fmaxf(amx, fabsf(g));
@@ -485,23 +525,38 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
     if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc2[0];
 }
 
-// A/B switch (default on; environment BM_BN_BWD_FUSED=0 or bm_act_bn_bwd_set_fused(0): the two-pass kernels)
+// A/B switch: 0 = the two-pass kernels, 1 = one pass with slabs of <= 2 560 float4 (10 per thread, 4 workgroups per
+// CU), 2 = slabs of <= 1 280 float4 (5 per thread, more workgroups per CU: a waiting workgroup's CU keeps streaming).
+// Default from the environment BM_BN_BWD_FUSED, else FUSED_DEFAULT_MODE.
+#define FUSED_DEFAULT_MODE 2
 static int g_bn_bwd_fused = -1;
-extern "C" int bm_act_bn_bwd_set_fused(int on) {
-    const int prev = g_bn_bwd_fused;
-    g_bn_bwd_fused = on ? 1 : 0;
+// test hook: polls before a workgroup gives up on its partners and computes their sums itself (0: at once)
+static unsigned g_fused_poll_limit = FUSED_POLL_LIMIT;
+extern "C" int bm_act_bn_bwd_set_poll_limit(int polls) {
+    const int prev = (int)g_fused_poll_limit;
+    g_fused_poll_limit = polls < 0 ? FUSED_POLL_LIMIT : (unsigned)polls;
     return prev;
 }
-
-// splits of the one-pass kernel: the smallest count whose per-split slab fits the registers; 0 = not covered
-static int fused_nsplit(int B, int C, int T) {
-    if (T % 4 != 0 || B <= 0 || (long)B * C * T >= 0xffffffffL) return 0;
+extern "C" int bm_act_bn_bwd_set_fused(int mode) {
+    const int prev = g_bn_bwd_fused;
+    g_bn_bwd_fused = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
+    return prev;
+}
+static int fused_mode() {
     if (g_bn_bwd_fused < 0) {
         const char* e = getenv("BM_BN_BWD_FUSED");
-        g_bn_bwd_fused = (e && e[0] == '0') ? 0 : 1;
+        g_bn_bwd_fused = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : FUSED_DEFAULT_MODE;
     }
-    if (!g_bn_bwd_fused) return 0;
-    const long TV = T / 4, cap = 256L * FUSED_MAXIT;
+    return g_bn_bwd_fused;
+}
+
+extern "C" int bm_bwd_nsplit(int B);
+// splits of the one-pass kernel: the smallest count whose per-split slab fits the registers; 0 = not covered
+static int fused_nsplit(int B, int C, int T, int* maxit) {
+    const int mode = fused_mode();
+    if (!mode || T % 4 != 0 || B <= 0 || (long)B * C * T >= 0xffffffffL) return 0;
+    const long TV = T / 4, cap = 256L * (mode == 1 ? 10 : 5);
+    if (maxit) *maxit = mode == 1 ? 10 : 5;
     if (TV > cap) return 0;
     for (int n = bm_bwd_nsplit(B); n <= NSPLIT_MAX && n <= B; ++n) {
         const long nb = ((long)B + n - 1) / n;          // the largest slab of `n` near-equal splits
@@ -509,7 +564,7 @@ static int fused_nsplit(int B, int C, int T) {
     }
     return 0;
 }
-extern "C" int bm_act_bn_bwd_fused_covers(int B, int C, int T) { return fused_nsplit(B, C, T) > 0; }
+extern "C" int bm_act_bn_bwd_fused_covers(int B, int C, int T) { return fused_nsplit(B, C, T, nullptr) > 0; }
 
 // out[c] = sum_split partial[c][split]
 __global__ void finalize_channel_sums_kernel(const double* __restrict__ partial, float* __restrict__ out,
@@ -529,10 +584,10 @@ extern "C" int bm_bwd_nsplit(int B) { return B >= 64 ? 8 : (B >= 8 ? 4 : 1); }
 static int gelu_grad_code(int act) { return act == BM_ACT_GELU ? BM_ACT_GELU_FASTGRAD : act; }
 
 // workspace: doubles, (2*C*nsplit) for the reduce partials + (C*nsplit) for the dy sums.
-// (+ the ticket / time-out / per-channel arrival words of the one-pass kernel; sized for its largest split count)
+// (sized for the largest split count of the one-pass kernel)
 extern "C" long bm_act_bn_bwd_workspace_bytes(int B, int C) {
     (void)B;
-    return (long)3 * C * NSPLIT_MAX * sizeof(double) + ((long)C + 8) * sizeof(unsigned);
+    return (long)3 * C * NSPLIT_MAX * sizeof(double);
 }
 
 extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* scale,
@@ -546,7 +601,8 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     BM_REQUIRE(!bn_train || (scale && shift && mean && invstd), "act_bn_bwd: train BN needs saved statistics");
     if ((long)B * C * T == 0) return BM_OK;
     const bool reduce = bn_train || (scale && (dgamma || dbeta));
-    const int nfused = (reduce && scale && shift && mean && invstd) ? fused_nsplit(B, C, T) : 0;
+    int maxit = 0;
+    const int nfused = (reduce && scale && shift && mean && invstd) ? fused_nsplit(B, C, T, &maxit) : 0;
     const int nsplit = nfused ? nfused : bm_bwd_nsplit(B);
     if (workspace_bytes < bm_act_bn_bwd_workspace_bytes(B, C))
         return bm_set_error(BM_ERR_WORKSPACE, "act_bn_bwd: workspace too small (%ld < %ld)", workspace_bytes,
@@ -559,12 +615,17 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
     act = gelu_grad_code(act);
     if (nfused) {
         // one pass: the slab stays in registers between the sums and the apply (see bn_bwd_fused_kernel)
-        unsigned* sync = (unsigned*)((double*)workspace + (long)3 * C * NSPLIT_MAX);
-        hipError_t e = hipMemsetAsync(sync, 0, ((size_t)C + 2) * sizeof(unsigned), s);
+        hipError_t e = hipMemsetAsync(partial, 0xff, (size_t)2 * C * nsplit * sizeof(double), s);
         if (e != hipSuccess) return bm_set_error((int)e, "act_bn_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3((unsigned)C * (unsigned)nsplit), dim3(256), 0, s, dout, y, scale,
-                           shift, mean, invstd, partial, sync, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit,
-                           act, leak, amax_dst, bm_fastdiv((unsigned)(T / 4)));
+        const dim3 fgrid((unsigned)C * (unsigned)nsplit);
+        if (maxit == 10)
+            hipLaunchKernelGGL(bn_bwd_fused_kernel<10>, fgrid, dim3(256), 0, s, dout, y, scale, shift, mean, invstd,
+                               (unsigned long long*)partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit, act,
+                               leak, amax_dst, bm_fastdiv((unsigned)(T / 4)), bm_fastdiv((unsigned)nsplit), g_fused_poll_limit);
+        else
+            hipLaunchKernelGGL(bn_bwd_fused_kernel<5>, fgrid, dim3(256), 0, s, dout, y, scale, shift, mean, invstd,
+                               (unsigned long long*)partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit, act,
+                               leak, amax_dst, bm_fastdiv((unsigned)(T / 4)), bm_fastdiv((unsigned)nsplit), g_fused_poll_limit);
     } else if (T % 4 == 0) {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,

@@ -126,7 +126,10 @@ def test_conv_outputs_stay_inside_their_buffers(H, B, Cin, M, KS, dil, T):
     with arena.active():
         wp = H.pack_conv_fwd(w, (T, dil))
         assert getattr(wp, "_bm_mode", "") == "f16x2", "shape not covered by the wide f16x2 conv: pick another"
-        pre, out, stats = H.conv_nn(x, wp, M, KS, dil, bias=b, res=res, want_pre=True, want_stats=True)
+        # the two forms the training step uses: pre-activation + BatchNorm partial sums (forward), and output + residual
+        # with the published maximum (data gradient)
+        pre, _, stats = H.conv_nn(x, wp, M, KS, dil, bias=b, want_pre=True, want_out=False, want_stats=True)
+        _, out, _ = H.conv_nn(x, wp, M, KS, dil, bias=b, res=res)
         amax_out = H.amax(out)            # the maximum the epilogue published (finalize launch included)
     arena.check(f"conv {Cin}->{M} k{KS} d{dil} T={T} B={B}")
     for t, name in ((pre, "pre"), (out, "out"), (stats, "stats"), (amax_out, "amax")):

@@ -276,7 +276,10 @@ def test_full_size_horizon_20_steps_against_oracle(steps: int = 20):
     round-off-level gradients excepted, see adam_params_close).  ~6 s of host time per oracle step on 32 threads."""
     from brainmagick_amd.solver import Solver
     c = synthetic.CONFIGS["cfg2"]
-    batches = [synthetic.make_config_batch("cfg2", seed=2036 + i, batch=256) for i in range(4)]
+    # one study: the recordings (and their sensor layouts) are shared by the batches, like in a real training stream
+    # (the layouts of a recording are cached by its identity, bm/models/common.py:196-222 does the same)
+    pool = synthetic.make_layouts(4, [c["C"]], torch.Generator().manual_seed(7))
+    batches = [synthetic.make_config_batch("cfg2", seed=2036 + i, batch=256, recordings=pool) for i in range(4)]
     model = _paper_model(c["C"], c["F"], c["S"], seed=2036)
     oracle = O.OracleModel(copy.deepcopy(model.state_dict()), O.CLIP_CONV_CFG, 320, c["F"])
     ban = torch.tensor([0.4, 0.6])
