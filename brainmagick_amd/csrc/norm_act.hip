@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // so the result is bit-identical) and goes on -- a partner that was never resident can therefore not dead-lock it, it
 // only makes it slower.  The sums are folded in split order by every workgroup alike: deterministic.
 // ------------------------------------------------------------------------------------------------
+#define FUSED_MAXIT 10            // float4 positions per thread held between the phases (80 VGPRs; 4 workgroups per CU)
 #define FUSED_POLL_LIMIT 192u
 #define FUSED_SENTINEL 0xffffffffffffffffull
 
@@ -375,7 +376,7 @@ __device__ __forceinline__ void fused_elem(float dv, float yv, float sc, float s
 }
 
 template <int MAXIT>
-__global__ __launch_bounds__(256, MAXIT > 6 ? 4 : 6) void bn_bwd_fused_kernel(
+__global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
     const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     unsigned long long* partial, int bn_train, float* __restrict__ dy, double* __restrict__ dy_partial,
@@ -525,214 +526,12 @@ __global__ __launch_bounds__(256, MAXIT > 6 ? 4 : 6) void bn_bwd_fused_kernel(
     if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc2[0];
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same one-pass scheme, SOFTWARE-PIPELINED over a persistent grid (mode 3): a workgroup walks the items
-// (channel, split) = blockIdx.x, blockIdx.x + gridDim.x, ... and keeps TWO slabs in registers -- while it computes the
-// sums of item j, waits for that channel's other splits and writes dy, the loads of item j + 1 are already in flight.
-// The stand-alone form above runs in rounds (every resident workgroup reads, then every one waits, then every one
-// writes: 3.1 TB/s); here the memory system never idles.  Same hand-off, same fallback (a partner that is late or not
-// resident is computed locally), same summation order: bit-identical results.
-// ------------------------------------------------------------------------------------------------
-template <int M>
-struct FusedSlab {
-    float4 d[M], v[M];
-    unsigned nvec;
-    int c, split, b0;
-    float sc, shf, mu, is;
-};
-
-template <int M>
-__device__ __forceinline__ unsigned fused_off(const FusedSlab<M>& s, int it, int C, int T, int TV, const BmFastDiv& div_tv) {
-    const unsigned e = (unsigned)it * 256u + threadIdx.x;
-    const unsigned ee = e < s.nvec ? e : 0u;
-    const unsigned bl = bm_div(ee, div_tv);
-    return ((unsigned)(s.b0 + (int)bl) * (unsigned)C + (unsigned)s.c) * (unsigned)T + (ee - bl * (unsigned)TV) * 4u;
-}
-
-template <int M>
-__device__ __forceinline__ void fused_load(FusedSlab<M>& s, int item, const float* __restrict__ dout,
-                                           const float* __restrict__ y, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, const float* __restrict__ mean,
-                                           const float* __restrict__ invstd, int B, int C, int T, int nsplit,
-                                           const BmFastDiv& div_tv, const BmFastDiv& div_ns) {
-    s.c = (int)bm_div((unsigned)item, div_ns);
-    s.split = item - s.c * nsplit;
-    s.b0 = (int)((long)B * s.split / nsplit);
-    const int b1 = (int)((long)B * (s.split + 1) / nsplit);
-    const int TV = T / 4;
-    s.nvec = (unsigned)(b1 - s.b0) * (unsigned)TV;
-    s.sc = scale[s.c]; s.shf = shift[s.c]; s.mu = mean[s.c]; s.is = invstd[s.c];
-#pragma unroll
-    for (int it = 0; it < M; ++it) {
-        const unsigned o = fused_off(s, it, C, T, TV, div_tv);
-        s.d[it] = *reinterpret_cast<const float4*>(dout + o);
-        s.v[it] = *reinterpret_cast<const float4*>(y + o);
-    }
-}
-
-template <int M>
-__device__ __forceinline__ void fused_item(
-    FusedSlab<M>& cur, FusedSlab<M>& nxt, int next_item, const float* __restrict__ dout, const float* __restrict__ y,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, unsigned long long* partial, int bn_train, float* __restrict__ dy,
-    double* __restrict__ dy_partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int T,
-    int nsplit, int act, float leak, const BmAmaxDst& amax_ws, const BmFastDiv& div_tv, const BmFastDiv& div_ns,
-    unsigned poll_limit, double* sh, float* amax_sh, float* k_sh, unsigned long long* part_sh, unsigned* missing_sh) {
-    const int TV = T / 4;
-    if (next_item >= 0)                  // the next slab's loads go out first: they land while this item is worked on
-        fused_load(nxt, next_item, dout, y, scale, shift, mean, invstd, B, C, T, nsplit, div_tv, div_ns);
-    const int c = cur.c, split = cur.split;
-    const float sc = cur.sc, shf = cur.shf, mu = cur.mu, is = cur.is;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int it = 0; it < M; ++it) {
-        const bool ok = (unsigned)it * 256u + threadIdx.x < cur.nvec;
-        float* dd = reinterpret_cast<float*>(&cur.d[it]);
-        float* vv = reinterpret_cast<float*>(&cur.v[it]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fused_elem(dd[i], vv[i], sc, shf, mu, is, act, leak, ok, dd[i], vv[i], s0, s1);
-    }
-    double acc[2] = {(double)s0, (double)s1};
-    block_sum<2>(acc, sh);
-    unsigned long long* chan = partial + (long)c * nsplit * 2;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned long long bits = __builtin_bit_cast(unsigned long long, acc[j]);
-            if (bits == FUSED_SENTINEL) bits = 0x7ff8000000000000ull;
-            __hip_atomic_store(chan + split * 2 + j, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            part_sh[split * 2 + j] = bits;
-        }
-    }
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const bool mine = lane < 2 * nsplit && (lane >> 1) != split;
-        unsigned long long bits = 0;
-        bool ready = !mine;
-        for (unsigned polls = 0;; ++polls) {
-            if (!ready) {
-                bits = __hip_atomic_load(chan + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ready = bits != FUSED_SENTINEL;
-            }
-            if (__all(ready) || polls >= poll_limit) break;
-            __builtin_amdgcn_s_sleep(64);
-        }
-        if (mine && ready) part_sh[lane] = bits;
-        const unsigned long long lagging = __ballot(!ready);
-        if (lane == 0) {
-            unsigned m = 0;
-            for (int k = 0; k < nsplit; ++k) m |= ((lagging >> (2 * k)) & 3ull) ? (1u << k) : 0u;
-            *missing_sh = m;
-        }
-    }
-    __syncthreads();
-    const unsigned missing = *missing_sh;
-    if (missing) {
-        for (int k = 0; k < nsplit; ++k) {
-            if (!((missing >> k) & 1u)) continue;
-            const int kb0 = (int)((long)B * k / nsplit), kb1 = (int)((long)B * (k + 1) / nsplit);
-            const unsigned knvec = (unsigned)(kb1 - kb0) * (unsigned)TV;
-            float t0 = 0.f, t1 = 0.f;
-            for (int it = 0; it < M; ++it) {
-                const unsigned e = (unsigned)it * 256u + threadIdx.x;
-                const bool ok = e < knvec;
-                const unsigned ee = ok ? e : 0u;
-                const unsigned bl = bm_div(ee, div_tv);
-                const unsigned o = ((unsigned)(kb0 + (int)bl) * (unsigned)C + (unsigned)c) * (unsigned)T + (ee - bl * (unsigned)TV) * 4u;
-                const float4 dv = *reinterpret_cast<const float4*>(dout + o);
-                const float4 yv = *reinterpret_cast<const float4*>(y + o);
-                const float* dd = reinterpret_cast<const float*>(&dv);
-                const float* vv = reinterpret_cast<const float*>(&yv);
-                float dz, xh;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fused_elem(dd[i], vv[i], sc, shf, mu, is, act, leak, ok, dz, xh, t0, t1);
-            }
-            double a2[2] = {(double)t0, (double)t1};
-            __syncthreads();
-            block_sum<2>(a2, sh);
-            if (threadIdx.x == 0) {
-                part_sh[2 * k + 0] = __builtin_bit_cast(unsigned long long, a2[0]);
-                part_sh[2 * k + 1] = __builtin_bit_cast(unsigned long long, a2[1]);
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double sdz = 0, sdzx = 0;
-        for (int k = 0; k < nsplit; ++k) {
-            sdz += __builtin_bit_cast(double, part_sh[2 * k + 0]);
-            sdzx += __builtin_bit_cast(double, part_sh[2 * k + 1]);
-        }
-        const double n = (double)B * T;
-        k_sh[0] = bn_train ? (float)(sdz / n) : 0.f;
-        k_sh[1] = bn_train ? (float)(sdzx / n) : 0.f;
-        if (split == 0) {
-            if (dgamma) dgamma[c] = (float)sdzx;
-            if (dbeta) dbeta[c] = (float)sdz;
-        }
-    }
-    __syncthreads();
-    const float k1 = k_sh[0], k2 = k_sh[1];
-    float sdy = 0.f, amx = 0.f;
-#pragma unroll
-    for (int it = 0; it < M; ++it) {
-        if ((unsigned)it * 256u + threadIdx.x < cur.nvec) {
-            const float* dd = reinterpret_cast<const float*>(&cur.d[it]);
-            const float* vv = reinterpret_cast<const float*>(&cur.v[it]);
-            float o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float g = sc * (dd[i] - k1 - vv[i] * k2);
-                o[i] = g;
-                sdy += g;
-                amx = fmaxf(amx, fabsf(g));
-            }
-            *reinterpret_cast<float4*>(dy + fused_off(cur, it, C, T, TV, div_tv)) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    bm_publish_amax_at(amx, amax_ws, amax_sh, (unsigned)split * (unsigned)C + (unsigned)c);
-    double acc2[1] = {(double)sdy};
-    block_sum<1>(acc2, sh);
-    if (threadIdx.x == 0 && dy_partial) dy_partial[(long)c * nsplit + split] = acc2[0];
-    __syncthreads();                     // the LDS words above are re-used by the next item
-}
-
-template <int M>
-__global__ __launch_bounds__(256, 3) void bn_bwd_stream_kernel(
-    const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    unsigned long long* partial, int bn_train, float* __restrict__ dy, double* __restrict__ dy_partial,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int T, int nsplit, int act, float leak,
-    BmAmaxDst amax_ws, BmFastDiv div_tv, BmFastDiv div_ns, unsigned poll_limit) {
-    __shared__ double sh[4 * 2];
-    __shared__ float amax_sh[4];
-    __shared__ float k_sh[2];
-    __shared__ unsigned long long part_sh[2 * NSPLIT_MAX];
-    __shared__ unsigned missing_sh;
-    const int items = C * nsplit, G = (int)gridDim.x;
-    int item = (int)blockIdx.x;
-    if (item >= items) return;
-    FusedSlab<M> sa, sb;
-    fused_load(sa, item, dout, y, scale, shift, mean, invstd, B, C, T, nsplit, div_tv, div_ns);
-    for (;;) {
-        fused_item(sa, sb, item + G < items ? item + G : -1, dout, y, scale, shift, mean, invstd, partial, bn_train, dy,
-                   dy_partial, dgamma, dbeta, B, C, T, nsplit, act, leak, amax_ws, div_tv, div_ns, poll_limit, sh,
-                   amax_sh, k_sh, part_sh, &missing_sh);
-        item += G;
-        if (item >= items) break;
-        fused_item(sb, sa, item + G < items ? item + G : -1, dout, y, scale, shift, mean, invstd, partial, bn_train, dy,
-                   dy_partial, dgamma, dbeta, B, C, T, nsplit, act, leak, amax_ws, div_tv, div_ns, poll_limit, sh,
-                   amax_sh, k_sh, part_sh, &missing_sh);
-        item += G;
-        if (item >= items) break;
-    }
-}
-
-// A/B switch: 0 = the two-pass kernels, 1 = one pass with slabs of <= 2 560 float4 (10 per thread, 4 workgroups per
-// CU), 2 = slabs of <= 1 280 float4 (5 per thread, more workgroups per CU: a waiting workgroup's CU keeps streaming),
-// 3 = slabs of <= 1 280 float4, software-pipelined over a persistent grid (bn_bwd_stream_kernel).
-// Default from the environment BM_BN_BWD_FUSED, else FUSED_DEFAULT_MODE.
-#define FUSED_DEFAULT_MODE 2
+// A/B switch: 0 = the two-pass kernels, 1 = one pass (default; environment BM_BN_BWD_FUSED).
+// Measured (profiles/r5_ab_notes.md): two passes 152-154 us stand-alone / ~118 us inside the step (the second pass
+// re-reads from the memory-side cache), one pass 113-118 us stand-alone, -0.2 ... -0.27 ms per training step.  Two more
+// forms were built, measured and removed: slabs of 5 float4 per thread with 6 workgroups per CU (119-125 us) and a
+// software-pipelined persistent grid holding two slabs per workgroup (153 us: every workgroup of the chip reaches its
+// hand-off at the same time, so nothing overlaps the ~7 us of hand-off latency per item).
 static int g_bn_bwd_fused = -1;
 // test hook: polls before a workgroup gives up on its partners and computes their sums itself (0: at once)
 static unsigned g_fused_poll_limit = FUSED_POLL_LIMIT;
@@ -743,13 +542,13 @@ extern "C" int bm_act_bn_bwd_set_poll_limit(int polls) {
 }
 extern "C" int bm_act_bn_bwd_set_fused(int mode) {
     const int prev = g_bn_bwd_fused;
-    g_bn_bwd_fused = mode < 0 ? -1 : (mode > 3 ? 3 : mode);
+    g_bn_bwd_fused = mode < 0 ? -1 : (mode ? 1 : 0);
     return prev;
 }
 static int fused_mode() {
     if (g_bn_bwd_fused < 0) {
         const char* e = getenv("BM_BN_BWD_FUSED");
-        g_bn_bwd_fused = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : FUSED_DEFAULT_MODE;
+        g_bn_bwd_fused = (e && e[0] == '0') ? 0 : 1;
     }
     return g_bn_bwd_fused;
 }
@@ -759,8 +558,8 @@ extern "C" int bm_bwd_nsplit(int B);
 static int fused_nsplit(int B, int C, int T, int* maxit) {
     const int mode = fused_mode();
     if (!mode || T % 4 != 0 || B <= 0 || (long)B * C * T >= 0xffffffffL) return 0;
-    const long TV = T / 4, cap = 256L * (mode == 1 ? 10 : 5);
-    if (maxit) *maxit = mode == 1 ? 10 : (mode == 2 ? 5 : -5);      // -5: the streaming kernel
+    const long TV = T / 4, cap = 256L * FUSED_MAXIT;
+    if (maxit) *maxit = FUSED_MAXIT;
     if (TV > cap) return 0;
     for (int n = bm_bwd_nsplit(B); n <= NSPLIT_MAX && n <= B; ++n) {
         const long nb = ((long)B + n - 1) / n;          // the largest slab of `n` near-equal splits
@@ -822,25 +621,9 @@ extern "C" int bm_act_bn_bwd(const float* dout, const float* y, const float* sca
         hipError_t e = hipMemsetAsync(partial, 0xff, (size_t)2 * C * nsplit * sizeof(double), s);
         if (e != hipSuccess) return bm_set_error((int)e, "act_bn_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
         const dim3 fgrid((unsigned)C * (unsigned)nsplit);
-        if (maxit == -5) {
-            static int wgs_per_cu = 0;
-            if (!wgs_per_cu) {
-                const char* e = getenv("BM_BN_BWD_WGS_PER_CU");
-                wgs_per_cu = (e && e[0] >= '1' && e[0] <= '8') ? e[0] - '0' : 3;
-            }
-            const unsigned items = (unsigned)C * (unsigned)nsplit, cap = 256u * (unsigned)wgs_per_cu;
-            hipLaunchKernelGGL(bn_bwd_stream_kernel<5>, dim3(items < cap ? items : cap), dim3(256), 0, s, dout, y, scale,
-                               shift, mean, invstd, (unsigned long long*)partial, bn_train, dy, dy_partial, dgamma, dbeta,
-                               B, C, T, nsplit, act, leak, amax_dst, bm_fastdiv((unsigned)(T / 4)),
-                               bm_fastdiv((unsigned)nsplit), g_fused_poll_limit);
-        } else if (maxit == 10)
-            hipLaunchKernelGGL(bn_bwd_fused_kernel<10>, fgrid, dim3(256), 0, s, dout, y, scale, shift, mean, invstd,
-                               (unsigned long long*)partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit, act,
-                               leak, amax_dst, bm_fastdiv((unsigned)(T / 4)), bm_fastdiv((unsigned)nsplit), g_fused_poll_limit);
-        else
-            hipLaunchKernelGGL(bn_bwd_fused_kernel<5>, fgrid, dim3(256), 0, s, dout, y, scale, shift, mean, invstd,
-                               (unsigned long long*)partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit, act,
-                               leak, amax_dst, bm_fastdiv((unsigned)(T / 4)), bm_fastdiv((unsigned)nsplit), g_fused_poll_limit);
+        hipLaunchKernelGGL(bn_bwd_fused_kernel<FUSED_MAXIT>, fgrid, dim3(256), 0, s, dout, y, scale, shift, mean, invstd,
+                           (unsigned long long*)partial, bn_train, dy, dy_partial, dgamma, dbeta, B, C, T, nsplit, act,
+                           leak, amax_dst, bm_fastdiv((unsigned)(T / 4)), bm_fastdiv((unsigned)nsplit), g_fused_poll_limit);
     } else if (T % 4 == 0) {
         if (reduce)
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, dout, y, scale, shift, mean,

@@ -1,6 +1,5 @@
 """HIP-event time of bm_act_bn_bwd (train-mode BatchNorm + GELU backward of one 320-channel layer at B = 256, T = 360)
-in its forms, interleaved: 0 = two passes, 1 / 2 = one pass with 10 / 5 float4 per thread, 3 = one pass, software-pipelined
-over a persistent grid (csrc/norm_act.hip; BM_BN_BWD_WGS_PER_CU sizes that grid)."""
+in its two forms, interleaved: 0 = two passes, 1 = one pass (csrc/norm_act.hip, bn_bwd_fused_kernel)."""
 import sys
 from pathlib import Path
 import torch
@@ -18,7 +17,7 @@ shift = -mean * scale
 other = torch.randn(64 << 20, device="cuda")           # 256 MB streamed between calls: nothing of a call stays cached
 res = {}
 for rnd in range(3):
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1):
         lib().bm_act_bn_bwd_set_fused(mode)
         ts = []
         for rep in range(12):
@@ -30,7 +29,7 @@ for rnd in range(3):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         res.setdefault(mode, []).append(sorted(ts)[len(ts) // 2])
-nbytes = {0: 5, 1: 3, 2: 3, 3: 3}
+nbytes = {0: 5, 1: 3}
 for mode, v in res.items():
     us = sorted(v)[1]
     print(f"mode {mode}: median {us:7.1f} us per call (rounds {[round(x, 1) for x in v]}), "

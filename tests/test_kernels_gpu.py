@@ -182,9 +182,7 @@ def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
     n = B * T
     ref = scale[None, :, None] * (dz - dz.sum((0, 2), keepdim=True) / n - xh * (dz * xh).sum((0, 2), keepdim=True) / n)
     results = [("two-pass", two)]
-    for mode in (1, 2, 3):                    # slabs of <= 10 / <= 5 float4 per thread; 3 = software-pipelined, persistent
-        if (T // 4) > 256 * (10 if mode == 1 else 5):
-            continue
+    for mode in (1,):
         one, again = run(mode), run(mode)
         for a, b in zip(one, again):
             assert a is None or torch.equal(a, b)                     # deterministic
