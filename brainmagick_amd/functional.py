@@ -19,6 +19,25 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_arange_cache = {}
+
+
+def _arange_i32(n: int, device, repeat: int = 1) -> torch.Tensor:
+    """torch.arange(n, int32).repeat(repeat) on `device`, built once per (n, repeat, device): the composed front end
+    asked for four of them per step (four tiny launches each time); they are constants."""
+    # (keyed by the stream as well: a tensor built on one stream is only ordered against kernels of that stream)
+    key = (n, repeat, device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    t = _arange_cache.get(key)
+    if t is None:
+        if len(_arange_cache) > 64:
+            _arange_cache.clear()
+        t = torch.arange(n, dtype=torch.int32, device=device)
+        if repeat != 1:
+            t = t.repeat(repeat)
+        _arange_cache[key] = t
+    return t
+
+
 def _conv_weight_grads(dy, x, weight, KS, dil, transposed_weight):
     """dW in the layout of the parameter: Conv1d [M,Cin,KS] or ConvTranspose1d(k=1) [Cin,M,1]; written straight into
     the optimizer's flat gradient bucket when the parameter has a registered destination (hip_ops.grad_destination)."""
@@ -223,7 +242,7 @@ class ChannelMergerFn(torch.autograd.Function):
         per_layout_heads = heads.dim() == 3
         assert not per_layout_heads or heads.shape[0] == U
         emb = H.fourier_emb(positions_u, D)
-        seg = torch.arange(U + 1, dtype=torch.int32, device=meg.device)
+        seg = _arange_i32(U + 1, meg.device)
         scores = H.gemm_nt(heads, emb, U, O, C, D, a_strides=(O * D if per_layout_heads else 0, D),
                            x_strides=(C * D, D), seg=seg, G=U, force_f32=True).view(U, O, C)
         weights = H.masked_softmax(scores, positions_u, ban_center, ban_radius)
@@ -247,7 +266,7 @@ class ChannelMergerFn(torch.autograd.Function):
             dweights = H.gemm_nt(dout, meg, B, O, C, T, 1, 1, order=order, seg=seg, G=U).view(U, O, C)
             dscores = H.softmax_bwd(weights, dweights)
             wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0, shape=(D, 1))
-            uidx = torch.arange(U, dtype=torch.int32, device=meg.device)
+            uidx = _arange_i32(U, meg.device)
             _, per_layout, _ = H.conv_nn(emb, wp, O, 1, 1, widx=uidx)        # [U, O, D]
             if ctx.per_layout_heads:
                 dheads = per_layout
@@ -288,7 +307,7 @@ class FusedFrontEndFn(torch.autograd.Function):
         dev = meg.device
         # spatial-attention weights per layout (as ChannelMergerFn)
         emb = H.fourier_emb(positions_u, Dp)
-        seg_u = torch.arange(U + 1, dtype=torch.int32, device=dev)
+        seg_u = _arange_i32(U + 1, dev)
         scores = H.gemm_nt(heads, emb, U, O, C, Dp, a_strides=(0, Dp), x_strides=(C * Dp, Dp), seg=seg_u,
                            G=U, force_f32=True).view(U, O, C)
         wm = H.masked_softmax(scores, positions_u, ban_center, ban_radius)              # [U, O, C]
@@ -296,7 +315,7 @@ class FusedFrontEndFn(torch.autograd.Function):
         _, p, _ = H.conv_nn(wm, H.pack_conv_fwd(w1), L, 1, 1)                           # [U, L, C]
         bcol = (b1 if b1 is not None else torch.zeros(L, device=dev)).view(1, L, 1).expand(U, L, 1)
         xp = torch.cat([p, bcol], dim=2).repeat_interleave(S, dim=0).contiguous()       # [U*S, L, C+1], pair = u*S + s
-        widx_p = torch.arange(S, dtype=torch.int32, device=dev).repeat(U)
+        widx_p = _arange_i32(S, dev, repeat=U)
         # Wc[u,s] = Ws[s]^T [P[u] | b1]
         _, wc, _ = H.conv_nn(xp, H.pack_weights(ws, S, D, L, 1, L * D, 1, D, 0), D, 1, 1, widx=widx_p)   # [U*S, D, C+1]
         bias_c = wc[:, :, C].contiguous()                                               # [U*S, D]
@@ -322,7 +341,7 @@ class FusedFrontEndFn(torch.autograd.Function):
         H.gemm_nt(dout, meg, B, D, C, T, 1, 1, order=order, seg=seg, G=P, out=gaug,
                   out_strides=(D * (C + 1), C + 1, 1, 0))
         gaug[:, :, C] = H.segment_sum_cols(H.time_sums_t(dout), order, seg).t()
-        seg_p = torch.arange(P + 1, dtype=torch.int32, device=dev)
+        seg_p = _arange_i32(P + 1, dev)
         dws = dw1 = db1 = dheads = None
         if ctx.needs_input_grad[4]:
             t1 = H.gemm_nt(xp, gaug, P, L, D, C + 1, seg=seg_p, G=P)                    # [P, L, D, 1]
@@ -339,7 +358,7 @@ class FusedFrontEndFn(torch.autograd.Function):
             _, dwm, _ = H.conv_nn(a_u, H.pack_conv_dgrad(w1), O, 1, 1)                  # [U, O, C+1]
             dscores = H.softmax_bwd(wm, dwm[:, :, :C].contiguous())
             wp = H.pack_weights(dscores, U, O, C, 1, O * C, C, 1, 0, shape=(Dp, 1))
-            uidx = torch.arange(U, dtype=torch.int32, device=dev)
+            uidx = _arange_i32(U, dev)
             _, per_layout, _ = H.conv_nn(emb, wp, O, 1, 1, widx=uidx)                  # [U, O, Dp]
             dheads = H.sum_over_batch(per_layout) if U > 1 else per_layout[0]
         dmeg = None
