@@ -29,4 +29,5 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
+python scripts/probe_bn_bwd.py > gpurun_out/${TAG}_bn_bwd_probe.txt 2>&1; cat gpurun_out/${TAG}_bn_bwd_probe.txt | tail -3
 head -3 gpurun_out/${TAG}_power_trace.txt | cut -c1-300
