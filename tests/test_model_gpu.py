@@ -317,6 +317,10 @@ def test_full_size_horizon_20_steps_against_oracle(steps: int = 20):
             assert float((d > 2 * lr).double().mean()) <= 1e-2 and float(d.max()) <= 2.1 * lr * steps, \
                 (k, float((d > 2 * lr).double().mean()), float(d.max()))
             worst = max(worst, (rel_l2(v, ref), k))
+        elif k.endswith("running_mean"):
+            # the batch mean carries the conv bias in front of the BatchNorm, whose gradient is analytically zero and
+            # whose Adam moves are therefore +-lr noise of either sign (is_noise_grad): up to 2 lr per step of drift
+            assert float(d.max()) <= 2.1 * lr * steps, (k, float(d.max()))
         else:
             assert rel_l2(v, ref) < 1e-3, (k, rel_l2(v, ref))
     print(f"full-size horizon: worst parameter rel-L2 after {steps} steps {worst[0]:.2e} ({worst[1]})")
