@@ -397,15 +397,19 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
 
     // phase 1: the slab into registers, all loads in flight before the first use
     float4 d[MAXIT], v[MAXIT];
-    unsigned off[MAXIT];                                                 // element offsets: B * C * T < 2^32 (host check)
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    // element offset of position `it` of this thread (B * C * T < 2^32, host check); recomputed for the stores of phase 2
+    // rather than kept: MAXIT registers decide between 4 and 3 workgroups per CU
+    auto offset = [&](int it) {
         const unsigned e = (unsigned)it * 256u + threadIdx.x;
         const unsigned ee = e < nvec ? e : 0u;                           // past the slab: re-read position 0 (unused)
         const unsigned bl = bm_div(ee, div_tv);
-        off[it] = ((unsigned)(b0 + (int)bl) * (unsigned)C + (unsigned)c) * (unsigned)T + (ee - bl * (unsigned)TV) * 4u;
-        d[it] = *reinterpret_cast<const float4*>(dout + off[it]);
-        v[it] = *reinterpret_cast<const float4*>(y + off[it]);
+        return ((unsigned)(b0 + (int)bl) * (unsigned)C + (unsigned)c) * (unsigned)T + (ee - bl * (unsigned)TV) * 4u;
+    };
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const unsigned o = offset(it);
+        d[it] = *reinterpret_cast<const float4*>(dout + o);
+        v[it] = *reinterpret_cast<const float4*>(y + o);
     }
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
                 sdy += g;
                 amx = fmaxf(amx, fabsf(g));
             }
-            *reinterpret_cast<float4*>(dy + off[it]) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dy + offset(it)) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
     bm_publish_amax_at(amx, amax_ws, amax_sh, (unsigned)split * (unsigned)C + (unsigned)c);
@@ -558,6 +562,8 @@ extern "C" int bm_bwd_nsplit(int B);
 static int fused_nsplit(int B, int C, int T, int* maxit) {
     const int mode = fused_mode();
     if (!mode || T % 4 != 0 || B <= 0 || (long)B * C * T >= 0xffffffffL) return 0;
+    // (slabs of 11 or 12 positions per thread -- 2.8 / 2.5 rounds of resident workgroups instead of 3.1 -- measure the
+    // same 115 us stand-alone and the same step: profiles/r5_ab_notes.md)
     const long TV = T / 4, cap = 256L * FUSED_MAXIT;
     if (maxit) *maxit = FUSED_MAXIT;
     if (TV > cap) return 0;
