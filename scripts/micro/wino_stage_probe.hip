@@ -1,0 +1,275 @@
+// What would the main loop of a Winograd F(2,3) conv cost on this datapath, in the BEST case -- every operand a
+// ready-made f16 plane staged by LDS-DMA, nothing transformed or split in the kernel -- next to the loop of today's
+// direct 3-tap conv (conv_nn_h2w.hip)?  Both variants are built from the production kernel's ingredients, on RANDOM
+// operands (the matrix pipe is power-limited: zeros would flatter both):
+//   * one workgroup of four wavefronts per CU (one per SIMD), 15 accumulator blocks of 32 x 32 per wavefront (240 AGPRs),
+//     45 x v_mfma_f32_32x32x16_f16 per stage, one instruction slot behind every MFMA (scheduling fence after each);
+//   * 16 fragment reads (ds_read_b128) per stage from the LDS buffer of the current stage;
+//   * the operand bytes of stage s + 1 by global_load_lds (1 KB per instruction), drained and a workgroup barrier
+//     at the end of the stage;
+//   * an epilogue that writes the tile's fp32 outputs.
+//
+//   direct   : 60 stages per 320 x 192 tile (20 channel chunks x 3 taps); per stage and wavefront 5 weight copies
+//              (20.5 KB per workgroup, an L2-resident 1.2 MB tensor) and, in one stage of three, the input window
+//              through registers (16 dword loads + 8 split pairs of 4 VALU + 4 LDS writes per thread); stores 245 KB;
+//   winograd : 20 stages per 160 x 192 HALF tile, wavefront = component (the same 5 x 3 block economy); per stage and
+//              wavefront 10 copies of transformed weights (41 KB per workgroup, L2-resident 1.6 MB) + 6 copies of
+//              transformed input planes (24.6 KB per workgroup, streamed from HBM); the four components are combined
+//              through LDS before the stores (60 ds_write_b128 + 60 ds_read_b128 + 240 VALU per lane); stores 123 KB;
+//              TWICE as many tiles for the same outputs.
+// Reported: cycles per stage, cycles per tile, and the time of one conv-sized launch (B = 256: 512 tiles / 1 024 half
+// tiles on 256 CUs).  The production conv takes 234 us for the same work.
+//   hipcc --offload-arch=gfx950 -O3 scripts/micro/wino_stage_probe.hip -o scripts/micro/bin/wino_stage_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+__device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo)
+        : "v"(x0), "v"(x1), "v"(s));
+}
+
+constexpr int NM = 45;                       // MFMAs per stage and wavefront (5 x 3 blocks x 3 products)
+// LDS (16-byte slots).  direct: A 3 buffers x 1 280 (weights of stage s + 2 in flight, like production) + X 2 x 1 024;
+// winograd: U 2 buffers x 2 560 (41 KB per stage: a third buffer does not fit) + V 3 buffers x 1 536 (the HBM stream gets
+// the two-stage lead) = 155.6 KB of the 160 KB.
+constexpr int D_A = 1280, D_X = 1024, D_TOTAL = 3 * D_A + 2 * D_X;
+constexpr int W_U = 2560, W_V = 1536, W_TOTAL = 2 * W_U + 3 * W_V;
+
+__device__ __forceinline__ float ld32(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+#define WAIT_X(N_)                                                                                 \
+    asm volatile("s_waitcnt vmcnt(%16)"                                                            \
+                 : "+v"(xreg[0]), "+v"(xreg[1]), "+v"(xreg[2]), "+v"(xreg[3]), "+v"(xreg[4]), "+v"(xreg[5]),   \
+                   "+v"(xreg[6]), "+v"(xreg[7]), "+v"(xreg[8]), "+v"(xreg[9]), "+v"(xreg[10]), "+v"(xreg[11]), \
+                   "+v"(xreg[12]), "+v"(xreg[13]), "+v"(xreg[14]), "+v"(xreg[15])                  \
+                 : "n"(N_) : "memory");
+#define DMA(SRC_, DST_) \
+    __builtin_amdgcn_global_load_lds((const void*)(SRC_), (__attribute__((address_space(3))) void*)(DST_), 16, 0, 0);
+
+template <bool WINO>
+__global__ __launch_bounds__(256, 1) void probe(const u32x4* __restrict__ wsrc, long wslots, const u32x4* __restrict__ xsrc,
+                                                long xslots, float* __restrict__ out, long long* __restrict__ clk,
+                                                int tiles_per_wg, int nstage) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x16 acc[5][3];
+    f16x8 af[2][5], bf[2][3];
+    float xreg[16];
+    unsigned ph[4], pw[4];
+    for (int i = 0; i < 16; ++i) xreg[i] = 1.f;
+    for (int i = 0; i < 5; ++i) af[0][i] = af[1][i] = f16x8{1, 2, 3, 4, 5, 6, 7, 8};
+    for (int i = 0; i < 3; ++i) bf[0][i] = bf[1][i] = f16x8{1, 1, 2, 2, 3, 3, 4, 4};
+    long long t_loop = 0, t_tile = 0;
+    const long wper = 64L * 16;                                    // slots one wavefront walks per stage (<= 10 copies)
+    long wpos = (wave * 131L * 64) % (wslots - wper);
+    const long xshare = xslots / gridDim.x;
+    const long xbeg = (long)blockIdx.x * xshare + wave * (xshare / 4);
+    const long xend = xbeg + xshare / 4 - 64 * 8;
+    long xpos = xbeg;
+    const float* xf = reinterpret_cast<const float*>(xsrc);
+    for (int tile = 0; tile < tiles_per_wg; ++tile) {
+        const long long t0 = clock64();
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+        // prologue: the operands of the first stage(s)
+        if (WINO) {
+            for (int i = 0; i < 10; ++i) DMA(wsrc + wpos + lane + 64 * i, lds + (wave * 10 + i) * 64)
+            for (int b = 0; b < 2; ++b)
+                for (int i = 0; i < 6; ++i) DMA(xsrc + xpos + lane + 64 * (6 * b + i), lds + 2 * W_U + b * W_V + (wave * 6 + i) * 64)
+        } else {
+            for (int b = 0; b < 2; ++b)
+                for (int i = 0; i < 5; ++i) DMA(wsrc + wpos + lane + 64 * (5 * b + i), lds + b * D_A + (wave * 5 + i) * 64)
+            for (int r = 0; r < 16; ++r) xreg[r] = ld32(xf + xpos * 4 + (long)r * 256 + tid);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const long long t1 = clock64();
+        int a3 = 0, v3 = 0, s = 0;                                 // s % 3 (A / V buffer rings), stage counter
+        // one stage with a COMPILE-TIME tap j (direct; like the production kernel's unrolled tap loop), winograd: j unused
+        auto stage = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int a_cur = a3 * D_A, a_nxt2 = (a3 == 0 ? 2 : a3 - 1) * D_A;          // (s + 2) % 3
+            const int u_cur = (s & 1) * W_U, u_nxt = W_U - u_cur;
+            const int v_cur = 2 * W_U + v3 * W_V, v_nxt2 = 2 * W_U + (v3 == 0 ? 2 : v3 - 1) * W_V;
+            const int xb = (s / 3) & 1;
+            const int x_cur = 3 * D_A + xb * D_X, x_nxt = 3 * D_A + (1 - xb) * D_X;
+            const u32x4* wp = wsrc + wpos + lane;
+            const u32x4* xp = xsrc + xpos + lane;
+            const float* xfp = xf + xpos * 4 + tid;
+            static_for<NM>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                constexpr int blk = n % 15, mt = blk / 3, nt = blk % 3, term = n / 15;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[term & 1][mt], bf[(term + 1) & 1][nt], acc[mt][nt], 0, 0, 0);
+                // 16 fragment reads, one per slot
+                if constexpr (n < 10)
+                    af[(n / 5) & 1][n % 5] = __builtin_bit_cast(f16x8, lds[(WINO ? u_cur + wave * 640 : a_cur) + (n * 64 + lane)]);
+                else if constexpr (n < 16)
+                    bf[(n / 3) & 1][n % 3] = __builtin_bit_cast(f16x8, lds[(WINO ? v_cur + wave * 384 : x_cur) + ((n - 10) * 64 + lane)]);
+                if constexpr (WINO) {
+                    // transformed weights of stage s + 1 (10 copies, L2-resident), planes of stage s + 2 (6 copies, HBM)
+                    if constexpr (n >= 16 && n < 26) DMA(wp + 64 * (n - 16), lds + u_nxt + (wave * 10 + n - 16) * 64)
+                    if constexpr (n >= 26 && n < 32) DMA(xp + 64 * (n - 26), lds + v_nxt2 + (wave * 6 + n - 26) * 64)
+                } else {
+                    // weights of stage s + 2 (5 copies); the window of the next chunk: 16 loads in the first tap's stage,
+                    // split pair by pair into the other X buffer in the last tap's stage
+                    if constexpr (n >= 16 && n < 21) DMA(wp + 64 * (n - 16), lds + a_nxt2 + (wave * 5 + n - 16) * 64)
+                    if constexpr (j == 0 && n >= 22 && n < 38) xreg[n - 22] = ld32(xfp + (n - 22) * 256);
+                    if constexpr (j == 2 && n >= 37 && n < 45) {
+                        constexpr int u = n - 37;
+                        if constexpr (u == 0) WAIT_X(10)
+                        if constexpr (u == 4) {
+                            lds[x_nxt + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                            lds[x_nxt + 256 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                        }
+                        split_pair(xreg[2 * u], xreg[2 * u + 1], 1024.f, ph[u & 3], pw[u & 3]);
+                        if constexpr (u == 7) {
+                            lds[x_nxt + 512 + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                            lds[x_nxt + 768 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            wpos += wper;
+            if (wpos > wslots - wper) wpos -= wslots - wper;
+            if (WINO || j == 0) {
+                xpos += WINO ? 64 * 6 : 64 * 4;                    // winograd: 6 KB per wavefront and stage; direct: 16 KB per workgroup and chunk
+                if (xpos > xend) xpos = xbeg;
+            }
+            // operands of stage s + 1 landed, workgroup barrier.  Younger VMEM that may stay in flight -- winograd: the 6
+            // plane copies of stage s + 2; direct: this stage's 5 weight copies (+ the 16 window loads of the chunk)
+            if constexpr (WINO) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (j == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(21) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            a3 = a3 == 2 ? 0 : a3 + 1;
+            v3 = v3 == 2 ? 0 : v3 + 1;
+            ++s;
+        };
+        if (WINO) {
+            for (int k = 0; k < nstage; ++k) stage(std::integral_constant<int, 1>{});
+        } else {
+            for (int k = 0; k < nstage / 3; ++k) {
+                stage(std::integral_constant<int, 0>{});
+                stage(std::integral_constant<int, 1>{});
+                stage(std::integral_constant<int, 2>{});
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const long long t2 = clock64();
+        // epilogue
+        // (uniform base in SGPRs + the lane as the one per-lane offset + an immediate: no per-store address registers)
+        float* ow = out + (((long)blockIdx.x * tiles_per_wg + tile) * 4 + wave) * (15 * 16 * 64);     // a tile's own output
+        if (WINO) {
+            // the four components (one per wavefront) meet in LDS: every wavefront writes its 15 blocks (60 x 16 bytes per
+            // lane), reads the other three's share of the outputs it combines (60 x 16 bytes), 2 adds per output
+            // (two phases of 30 x 16 bytes per lane: the 245 KB of a workgroup's components do not fit the LDS at once)
+            static_for<2>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int p = decltype(pc)::value;
+                static_for<30>([&](auto ec) __attribute__((always_inline)) {
+                    constexpr int e = p * 30 + decltype(ec)::value, blk = e / 4, q = e % 4;
+                    u32x4 v;
+                    v[0] = __builtin_bit_cast(unsigned, acc[blk / 3][blk % 3][4 * q]);
+                    v[1] = __builtin_bit_cast(unsigned, acc[blk / 3][blk % 3][4 * q + 1]);
+                    v[2] = __builtin_bit_cast(unsigned, acc[blk / 3][blk % 3][4 * q + 2]);
+                    v[3] = __builtin_bit_cast(unsigned, acc[blk / 3][blk % 3][4 * q + 3]);
+                    lds[(wave * 30 + decltype(ec)::value) * 64 + lane] = v;
+                });
+                __syncthreads();
+                static_for<30>([&](auto ec) __attribute__((always_inline)) {
+                    constexpr int e = p * 30 + decltype(ec)::value, blk = e / 4, q = e % 4;
+                    const u32x4 v = lds[(((wave + 1 + e % 3) & 3) * 30 + decltype(ec)::value) * 64 + lane];
+                    acc[blk / 3][blk % 3][4 * q] += __builtin_bit_cast(float, v[0]) - __builtin_bit_cast(float, v[1]);
+                    acc[blk / 3][blk % 3][4 * q + 1] += __builtin_bit_cast(float, v[2]) + __builtin_bit_cast(float, v[3]);
+                });
+                __syncthreads();
+            });
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) (ow + (i * 3 + k) * 8 * 64)[r * 64 + lane] = acc[i][k][r] + acc[i][k][r + 8];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) (ow + (i * 3 + k) * 16 * 64)[r * 64 + lane] = acc[i][k][r];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const long long t3 = clock64();
+        t_loop += t2 - t1;
+        t_tile += t3 - t0;
+    }
+    if (tid == 0 && blockIdx.x == 7) { clk[0] = t_loop; clk[1] = t_tile; }
+}
+
+template <bool WINO>
+static void run(const char* name, const u32x4* w, long wslots, const u32x4* x, long xslots, float* out,
+                long long* clk, int tiles_per_wg, int nstage) {
+    const int lds_bytes = (WINO ? W_TOTAL : D_TOTAL) * 16;
+    hipFuncSetAttribute((const void*)probe<WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    long long c[2] = {0, 0};
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(probe<WINO>, dim3(256), dim3(256), lds_bytes, 0, w, wslots, x, xslots, out, clk, tiles_per_wg, nstage);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2 && ms < best) { best = ms; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost); }
+    }
+    printf("%-9s %2d tiles per CU x %2d stages: %8.1f us per launch; per tile %7.0f cycles, main loop %7.0f = %6.0f per stage "
+           "(45 MFMAs = 1440)\n", name, tiles_per_wg, nstage, best * 1e3, (double)c[1] / tiles_per_wg,
+           (double)c[0] / tiles_per_wg, (double)c[0] / tiles_per_wg / nstage);
+}
+
+int main() {
+    const long wslots = (2L << 20) / 16;               // 2 MB of "weights": L2-resident
+    const long xslots = (1024L << 20) / 16;            // 1 GB of "activations": streamed from HBM
+    std::vector<unsigned short> h(8 << 20);
+    srand(1);
+    for (auto& v : h) {                                // random f16 in [-2, 2): sign, exponent 12..15, random mantissa
+        v = (unsigned short)(((rand() & 1) << 15) | ((12 + (rand() & 3)) << 10) | (rand() & 0x3ff));
+    }
+    u32x4 *w, *x; float* out; long long* clk;
+    hipMalloc(&w, wslots * 16); hipMalloc(&x, xslots * 16); hipMalloc(&out, 256L * 4 * 4 * 15 * 16 * 64 * 4); hipMalloc(&clk, 16);
+    hipMemcpy(w, h.data(), wslots * 16, hipMemcpyHostToDevice);
+    for (long off = 0; off < xslots * 16; off += (long)h.size() * 2)
+        hipMemcpy((char*)x + off, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    // one conv-sized launch at B = 256: 512 tiles of 320 x 192 / 1 024 half tiles of 160 x 192 on 256 CUs
+    run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
+    run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
+    run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
+    run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
+    return 0;
+}
