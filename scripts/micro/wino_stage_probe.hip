@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* __restrict__ wsrc, 
     long wpos = (wave * 131L * 64) % (wslots - wper);
     const long xshare = xslots / gridDim.x;
     const long xbeg = (long)blockIdx.x * xshare + wave * (xshare / 4);
-    const long xend = xbeg + xshare / 4 - 64 * 8;
+    const long xend = xbeg + xshare / 4 - 64 * 48;                 // a stage reaches up to 1 024 slots past its position
     long xpos = xbeg;
     const float* xf = reinterpret_cast<const float*>(xsrc);
     for (int tile = 0; tile < tiles_per_wg; ++tile) {
