@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <utility>
 #include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,17 +54,6 @@ constexpr int NM = 45;                       // MFMAs per stage and wavefront (5
 constexpr int D_A = 1280, D_X = 1024, D_TOTAL = 3 * D_A + 2 * D_X;
 constexpr int W_U = 2560, W_V = 1536, W_TOTAL = 2 * W_U + 3 * W_V;
 
-__device__ __forceinline__ float ld32(const float* p) {
-    float v;
-    asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
-    return v;
-}
-#define WAIT_X(N_)                                                                                 \
-    asm volatile("s_waitcnt vmcnt(%16)"                                                            \
-                 : "+v"(xreg[0]), "+v"(xreg[1]), "+v"(xreg[2]), "+v"(xreg[3]), "+v"(xreg[4]), "+v"(xreg[5]),   \
-                   "+v"(xreg[6]), "+v"(xreg[7]), "+v"(xreg[8]), "+v"(xreg[9]), "+v"(xreg[10]), "+v"(xreg[11]), \
-                   "+v"(xreg[12]), "+v"(xreg[13]), "+v"(xreg[14]), "+v"(xreg[15])                  \
-                 : "n"(N_) : "memory");
 #define DMA(SRC_, DST_) \
     __builtin_amdgcn_global_load_lds((const void*)(SRC_), (__attribute__((address_space(3))) void*)(DST_), 16, 0, 0);
 
@@ -105,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* __restrict__ wsrc, 
         } else {
             for (int b = 0; b < 2; ++b)
                 for (int i = 0; i < 5; ++i) DMA(wsrc + wpos + lane + 64 * (5 * b + i), lds + b * D_A + (wave * 5 + i) * 64)
-            for (int r = 0; r < 16; ++r) xreg[r] = ld32(xf + xpos * 4 + (long)r * 256 + tid);
+            for (int r = 0; r < 16; ++r) xreg[r] = xf[xpos * 4 + (long)r * 256 + tid];
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const long long t1 = clock64();
@@ -138,10 +128,9 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* __restrict__ wsrc, 
                     // weights of stage s + 2 (5 copies); the window of the next chunk: 16 loads in the first tap's stage,
                     // split pair by pair into the other X buffer in the last tap's stage
                     if constexpr (n >= 16 && n < 21) DMA(wp + 64 * (n - 16), lds + a_nxt2 + (wave * 5 + n - 16) * 64)
-                    if constexpr (j == 0 && n >= 22 && n < 38) xreg[n - 22] = ld32(xfp + (n - 22) * 256);
+                    if constexpr (j == 0 && n >= 22 && n < 38) xreg[n - 22] = xfp[(n - 22) * 256];      // compiler-visible: it counts the wait
                     if constexpr (j == 2 && n >= 37 && n < 45) {
                         constexpr int u = n - 37;
-                        if constexpr (u == 0) WAIT_X(10)
                         if constexpr (u == 4) {
                             lds[x_nxt + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]};
                             lds[x_nxt + 256 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]};
@@ -235,7 +224,8 @@ template <bool WINO>
 static void run(const char* name, const u32x4* w, long wslots, const u32x4* x, long xslots, float* out,
                 long long* clk, int tiles_per_wg, int nstage) {
     const int lds_bytes = (WINO ? W_TOTAL : D_TOTAL) * 16;
-    hipFuncSetAttribute((const void*)probe<WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    CK(hipFuncSetAttribute((const void*)probe<WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    printf("%s: launching with %d bytes of LDS\n", name, lds_bytes); fflush(stdout);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
@@ -244,7 +234,8 @@ static void run(const char* name, const u32x4* w, long wslots, const u32x4* x, l
         hipEventRecord(e0);
         hipLaunchKernelGGL(probe<WINO>, dim3(256), dim3(256), lds_bytes, 0, w, wslots, x, xslots, out, clk, tiles_per_wg, nstage);
         hipEventRecord(e1);
-        hipEventSynchronize(e1);
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep >= 2 && ms < best) { best = ms; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost); }
     }
@@ -262,14 +253,15 @@ int main() {
         v = (unsigned short)(((rand() & 1) << 15) | ((12 + (rand() & 3)) << 10) | (rand() & 0x3ff));
     }
     u32x4 *w, *x; float* out; long long* clk;
-    hipMalloc(&w, wslots * 16); hipMalloc(&x, xslots * 16); hipMalloc(&out, 256L * 4 * 4 * 15 * 16 * 64 * 4); hipMalloc(&clk, 16);
-    hipMemcpy(w, h.data(), wslots * 16, hipMemcpyHostToDevice);
+    CK(hipMalloc(&w, wslots * 16)); CK(hipMalloc(&x, xslots * 16)); CK(hipMalloc(&out, 256L * 4 * 4 * 15 * 16 * 64 * 4)); CK(hipMalloc(&clk, 16));
+    CK(hipMemcpy(w, h.data(), wslots * 16, hipMemcpyHostToDevice));
     for (long off = 0; off < xslots * 16; off += (long)h.size() * 2)
-        hipMemcpy((char*)x + off, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        CK(hipMemcpy((char*)x + off, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     // one conv-sized launch at B = 256: 512 tiles of 320 x 192 / 1 024 half tiles of 160 x 192 on 256 CUs
-    run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
-    run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
-    run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
-    run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
+    const char* only = getenv("PROBE_ONLY");
+    for (int rep = 0; rep < 2; ++rep) {
+        if (!only || only[0] == 'd') run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
+        if (!only || only[0] == 'w') run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
+    }
     return 0;
 }
