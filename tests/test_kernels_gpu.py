@@ -195,6 +195,20 @@ def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
             lib().bm_act_bn_bwd_set_poll_limit(limit)
         for a, b in zip(one, alone):
             assert a is None or torch.equal(a, b), f"mode {mode}: the fallback path rounds differently"
+        if B * C * T >= 1 << 24:
+            # the hand-off under UNEVEN load (cdna_hip_programming.md, Guideline 16: "test every hand-off under uneven
+            # load"): a second stream streams 512 MB per launch through the chip while the kernel runs, so the
+            # workgroups of a channel start and finish at different times -- same bits
+            side = torch.cuda.Stream()
+            noise = torch.zeros(64 << 20, device="cuda")
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(24):
+                    noise.add_(1.0)
+            loaded = run(mode)
+            side.synchronize()
+            for a, b in zip(one, loaded):
+                assert a is None or torch.equal(a, b), f"mode {mode}: different bits under concurrent load"
         assert rel_l2(one[0], two[0]) < 2e-6
         assert float(one[4].max()) == float(one[0].abs().max())      # the published maximum is that of what was written
         if one[5] is not None:
