@@ -17,6 +17,14 @@
 //              transformed input planes (24.6 KB per workgroup, streamed from HBM); the four components are combined
 //              through LDS before the stores (60 ds_write_b128 + 60 ds_read_b128 + 240 VALU per lane); stores 123 KB;
 //              TWICE as many tiles for the same outputs.
+//   rega     : (round 6) the direct conv with the WEIGHT operand off the LDS path: every wavefront fetches its own
+//              A fragments (2 planes x 5 row blocks x 1 KB) with buffer_load_dwordx4 straight from L2 into a second
+//              fragment register set, one stage ahead (the packed layout [plane][group][Mpad] x 16 B already is
+//              fragment order: a lane's slot is h * Mpad + row); LDS holds only the two X window buffers, so the
+//              workgroup meets at ONE barrier per 16-channel chunk (3 stages) instead of one per stage; B fragments
+//              double-buffered as well (read during the previous stage).  Same MFMA interleave, same window path, same
+//              epilogue.  `stagger` > 0: workgroup group (blockIdx / 8) % 4 starts stagger x group cycles late, so that
+//              the groups' store drains do not meet on the HBM write path.
 // Reported: cycles per stage, cycles per tile, and the time of one conv-sized launch (B = 256: 512 tiles / 1 024 half
 // tiles on 256 CUs).  The production conv takes 234 us for the same work.
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/wino_stage_probe.hip -o scripts/micro/bin/wino_stage_probe
@@ -45,6 +53,16 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned
         "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(hi), "=&v"(lo)
         : "v"(x0), "v"(x1), "v"(s));
+}
+
+// the two halves of split_pair as separate statements (2 VALU each), so that they can sit in different MFMA slots
+__device__ __forceinline__ void split_hi(float x0, float x1, float s, unsigned& hi) {
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(hi) : "v"(x0), "v"(x1), "v"(s));
+}
+__device__ __forceinline__ void split_lo(float x0, float x1, float s, unsigned hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(hi), "v"(x0), "v"(x1), "v"(s));
 }
 
 constexpr int NM = 45;                       // MFMAs per stage and wavefront (5 x 3 blocks x 3 products)
@@ -220,6 +238,263 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* __restrict__ wsrc, 
     if (tid == 0 && blockIdx.x == 7) { clk[0] = t_loop; clk[1] = t_tile; }
 }
 
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+constexpr int R_MPAD = 320;                  // rows of the packed weight planes
+constexpr int R_STAGE = 2 * 2 * R_MPAD;      // 16-byte slots of one stage's slab: [plane][8-channel group][Mpad]
+constexpr int R_X = 1024;                    // slots of one X window buffer
+constexpr int R_TOTAL = 3 * R_X + 1;              // three X buffers (two used without FLAGS 32) + the flag slot
+
+// FLAGS (ablation of the rega stage): 1 = no A loads, 2 = no window path, 4 = no barrier, 8 = no B reads,
+// 16 = the A loads are issued but the MFMAs read a constant fragment set (issue cost without the wait for the data),
+// 64 = THREE A register sets, the loads run two stages ahead (VMEM returns in order: an L2-hit A load queued behind the
+//      HBM-miss window loads waits for them), 128 = the window loads in two batches of 8 (stages j = 2 of the previous chunk and
+//      j = 0) right behind the A loads instead of 16 in one stage,
+// 256 = the A loads every 4th slot (all wavefronts in the same slots), 512 = every 4th slot, wavefront w in slots 4 k + w (the
+//      main loop is compiled once per wavefront index): the four wavefronts leave a barrier in lockstep and would otherwise
+//      hand the CU's one texture-address path four 1 KB loads per 32-cycle slot, twice what it takes; the window loads fill
+//      the other three slots of a group,
+// 1024 (with 256 / 512) = the window split two VALU at a time in the free slots of the second tap's stage (one LDS write per
+//      slot) instead of whole 4-VALU pairs + two writes in every other slot; B reads in the free slots of the last groups,
+// 32 = no s_barrier in the loop: three X buffers, a wavefront raises an LDS flag behind its window writes and the readers
+//      of the next chunk check the four flags (a wavefront may run a chunk ahead of its neighbours)
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void probe_rega(const u32x4* __restrict__ wsrc, long wslots, const u32x4* __restrict__ xsrc,
+                                                     long xslots, float* __restrict__ out, long long* __restrict__ clk,
+                                                     int tiles_per_wg, int nstage, int stagger) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, nl = lane & 31, h = lane >> 5;
+    f32x16 acc[5][3];
+    f16x8 af[3][2][5], bf[2][2][3];                                // [register set][plane][block]; the third A set: FLAGS 64
+    f16x8 afc[2][5];
+    float xreg[16];
+    unsigned ph[8], pw[8];
+    for (int i = 0; i < 16; ++i) xreg[i] = 1.f;
+    for (int i = 0; i < 10; ++i) afc[i / 5][i % 5] = __builtin_bit_cast(f16x8, wsrc[(i * 64 + lane) * 3 + 1]);
+    volatile int* flags = reinterpret_cast<volatile int*>(lds + 3 * R_X);
+    if (tid < 4) flags[tid] = 0;
+    __syncthreads();
+    int chunk_abs = 0;                                             // chunks done by this workgroup (flag values)
+    long long t_loop = 0, t_tile = 0;
+    const long long w_begin = wall_clock64(), c_begin = clock64();
+    if (stagger > 0) {
+        const int grp = (blockIdx.x >> 3) & 3;
+        const long long tw = clock64() + (long long)grp * stagger;
+        while (clock64() < tw) __builtin_amdgcn_s_sleep(16);
+    }
+    const __amdgpu_buffer_rsrc_t wr = mk_rsrc(wsrc, (unsigned)(wslots * 16));
+    const int nslab = (int)(wslots / R_STAGE);                     // stages' worth of slabs in the weight buffer
+    const int wvoff = (h * R_MPAD + wm * 160 + nl) * 16;           // the lane's slot inside a (plane) run pair
+    const long xshare = xslots / gridDim.x;
+    const long xbeg = (long)blockIdx.x * xshare + wave * (xshare / 4);
+    const long xend = xbeg + xshare / 4 - 64 * 48;
+    long xpos = xbeg;
+    const float* xf = reinterpret_cast<const float*>(xsrc);
+    int slab = 0;                                                  // slab index of the stage whose A is fetched next
+    // A fragments of the stage in slab `SL_` into register set SET_, plane P_, row block MT_ (one 1 KB wave load)
+#define LOAD_A(SET_, P_, MT_, SL_)                                                                            \
+    af[SET_][P_][MT_] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(                       \
+        wr, wvoff + (MT_) * 512, ((SL_) * 2 + (P_)) * (2 * R_MPAD * 16), 0));
+    auto body = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W = decltype(wc)::value;
+    for (int tile = 0; tile < tiles_per_wg; ++tile) {
+        const long long t0 = clock64();
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+        // prologue: A of stage 0 into set 0, the window of chunk 0 split into X buffer 0, B of stage 0 into set 0
+        static_for<10>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            LOAD_A(0, 1 - i / 5, i % 5, slab)
+            if constexpr ((FLAGS & (1 | 64)) != 0) LOAD_A(1, 1 - i / 5, i % 5, slab + 1)      // ablation: both sets hold real data; 64: stage 1
+        });
+        slab = slab + 1 == nslab ? 0 : slab + 1;
+        if constexpr ((FLAGS & 64) != 0) slab = slab + 1 == nslab ? 0 : slab + 1;
+        for (int r = 0; r < 16; ++r) xreg[r] = xf[xpos * 4 + (long)r * 256 + tid];
+        static_for<8>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            split_pair(xreg[2 * u], xreg[2 * u + 1], 1024.f, ph[u & 3], pw[u & 3]);
+            if constexpr (u == 3) { lds[tid] = u32x4{ph[0], ph[1], ph[2], ph[3]}; lds[256 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]}; }
+            if constexpr (u == 7) { lds[512 + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]}; lds[768 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]}; }
+        });
+        __syncthreads();
+        static_for<6>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            bf[0][i / 3][i % 3] = __builtin_bit_cast(f16x8, lds[i * 64 + lane]);
+            if constexpr ((FLAGS & 8) != 0) bf[1][i / 3][i % 3] = __builtin_bit_cast(f16x8, lds[i * 64 + 2 + lane]);
+        });
+        const long long t1 = clock64();
+        int s = 0;
+        // stage with compile-time tap J and register-set parity PAR
+        auto stage = [&](auto jc, auto pc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, par = decltype(pc)::value;
+            constexpr int aset = (FLAGS & 64) ? j : par, aset_ld = (FLAGS & 64) ? (j + 2) % 3 : par ^ 1;
+            const int chunk = s / 3;
+            constexpr int NXB = (FLAGS & 32) ? 3 : 2;
+            const int x_nxt_stage = (((j == 2 ? chunk + 1 : chunk)) % NXB) * R_X;   // X buffer of stage s + 1
+            const int x_wr = ((chunk + 1) % NXB) * R_X;                            // X buffer of the next chunk
+            const float* xfp = xf + xpos * 4 + tid;
+            const int sl = slab;
+            static_for<NM>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                constexpr int blk = n % 15, mt = blk / 3, nt = blk % 3, term = n / 15;
+                constexpr int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;      // lo*hi, hi*lo, hi*hi
+                if constexpr ((FLAGS & 16) != 0)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[pa][mt], bf[par][pb][nt], acc[mt][nt], 0, 0, 0);
+                else
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[aset][pa][mt], bf[par][pb][nt], acc[mt][nt], 0, 0, 0);
+                // A of stage s + 1 (FLAGS 64: s + 2) -> the other register set: 10 wave loads, one per slot
+                constexpr bool SPREAD = (FLAGS & (256 | 512)) != 0;
+                constexpr int sub = SPREAD ? (n % 4 - W + 4) % 4 : 0, grp = n / 4;
+                if constexpr (!SPREAD && n < 10 && !(FLAGS & 1)) LOAD_A(aset_ld, 1 - n / 5, n % 5, sl)          // A.lo first: the first term uses it
+                if constexpr (SPREAD && sub == 0 && grp < 10 && !(FLAGS & 1)) LOAD_A(aset_ld, 1 - grp / 5, grp % 5, sl)
+                if constexpr (SPREAD && sub != 0 && grp * 3 + sub - 1 < 16 && !(FLAGS & 2) && j == 0) xreg[grp * 3 + sub - 1] = xfp[(grp * 3 + sub - 1) * 256];
+                // the window of the next chunk: 16 loads in the first tap's stage, split + written in the second tap's
+                if constexpr (!(FLAGS & (2 | 128 | 256 | 512)) && j == 0 && n >= 12 && n < 28) xreg[n - 12] = xfp[(n - 12) * 256];
+                if constexpr ((FLAGS & 128) && !(FLAGS & 2) && j == 2 && n >= 10 && n < 18) xreg[n - 10] = xfp[(n - 10 + 16) * 256];
+                if constexpr ((FLAGS & 128) && !(FLAGS & 2) && j == 0 && n >= 10 && n < 18) xreg[n - 2] = xfp[(n - 2) * 256];
+                if constexpr ((FLAGS & 1024) && SPREAD && !(FLAGS & 2) && j == 1 && sub != 0) {
+                    constexpr int f = grp * 3 + sub - 1;
+                    if constexpr (f < 16) {
+                        constexpr int u = f / 2;
+                        if constexpr (f % 2 == 0) split_hi(xreg[2 * u], xreg[2 * u + 1], 1024.f, ph[u]);
+                        else split_lo(xreg[2 * u], xreg[2 * u + 1], 1024.f, ph[u], pw[u]);
+                    }
+                    if constexpr (f == 9) lds[x_wr + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                    if constexpr (f == 10) lds[x_wr + 256 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                    if constexpr (f == 16) lds[x_wr + 512 + tid] = u32x4{ph[4], ph[5], ph[6], ph[7]};
+                    if constexpr (f == 17) lds[x_wr + 768 + tid] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+                }
+                if constexpr (!(FLAGS & (2 | 1024)) && j == 1 && n >= 12 && n < 28 && ((n - 12) & 1) == 0) {
+                    constexpr int u = (n - 12) / 2;
+                    if constexpr (u == 4) {
+                        lds[x_wr + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                        lds[x_wr + 256 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                    }
+                    split_pair(xreg[2 * u], xreg[2 * u + 1], 1024.f, ph[u & 3], pw[u & 3]);
+                    if constexpr (u == 7) {
+                        lds[x_wr + 512 + tid] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+                        lds[x_wr + 768 + tid] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+                        if constexpr ((FLAGS & 32) != 0) {                       // LDS executes a wavefront's operations in order
+                            asm volatile("" ::: "memory");
+                            if (lane == 0) flags[wave] = chunk_abs + 1;
+                        }
+                    }
+                }
+                if constexpr ((FLAGS & 32) != 0 && j == 2 && n == 32) {          // every wavefront's share of the next window is in LDS
+                    for (;;) {
+                        const int f0 = flags[0], f1 = flags[1], f2 = flags[2], f3 = flags[3];
+                        const int lo01 = f0 < f1 ? f0 : f1, lo23 = f2 < f3 ? f2 : f3;
+                        if (__builtin_amdgcn_readfirstlane(lo01 < lo23 ? lo01 : lo23) > chunk_abs) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                // B of stage s + 1 -> the other register set: 6 fragment reads
+                constexpr bool BSLOT = (FLAGS & 1024) ? (sub != 0 && grp >= 8 && grp < 10) : (n >= 34 && n < 40);
+                if constexpr (BSLOT && !(FLAGS & 8)) {
+                    constexpr int i = (FLAGS & 1024) ? (grp - 8) * 3 + sub - 1 : n - 34;
+                    bf[par ^ 1][i / 3][i % 3] = __builtin_bit_cast(f16x8, lds[x_nxt_stage + (i / 3) * 512 + (i % 3) * 32 + ((j + 1) % 3) * 2 + lane]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            slab = slab + 1 == nslab ? 0 : slab + 1;
+            if (j == 0) {
+                xpos += 64 * 4;
+                if (xpos > xend) xpos = xbeg;
+            }
+            // the window of the next chunk is complete in LDS (every wavefront wrote its columns): ONE barrier per chunk
+            if constexpr (j == 1 && !(FLAGS & (4 | 32))) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (j == 2) ++chunk_abs;
+            ++s;
+        };
+        for (int k = 0; k < nstage / 6; ++k) {
+            stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const long long t2 = clock64();
+        float* ow = out + (((long)blockIdx.x * tiles_per_wg + tile) * 4 + wave) * (15 * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) (ow + (i * 3 + k) * 16 * 64)[r * 64 + lane] = acc[i][k][r];
+        if constexpr ((FLAGS & 16) != 0) {
+            float keep = 0.f;
+            for (int q = 0; q < 30; ++q) keep += (float)af[q / 10][(q / 5) & 1][q % 5][0];
+            ow[lane] = keep;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const long long t3 = clock64();
+        t_loop += t2 - t1;
+        t_tile += t3 - t0;
+    }
+    };
+    if constexpr ((FLAGS & 512) != 0) {
+        switch (wave) {
+            case 0: body(std::integral_constant<int, 0>{}); break;
+            case 1: body(std::integral_constant<int, 1>{}); break;
+            case 2: body(std::integral_constant<int, 2>{}); break;
+            default: body(std::integral_constant<int, 3>{}); break;
+        }
+    } else body(std::integral_constant<int, 0>{});
+#undef LOAD_A
+    if (tid == 0) { clk[4 * blockIdx.x] = t_loop; clk[4 * blockIdx.x + 1] = t_tile; clk[4 * blockIdx.x + 2] = wall_clock64() - w_begin; clk[4 * blockIdx.x + 3] = clock64() - c_begin; }
+}
+
+template <int FLAGS>
+static void run_rega(const u32x4* w, long wslots, const u32x4* x, long xslots, float* out, long long* clk,
+                     int tiles_per_wg, int nstage, int stagger) {
+    const int lds_bytes = R_TOTAL * 16;
+    CK(hipFuncSetAttribute((const void*)probe_rega<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    std::vector<long long> c(4 * 256), cb(4 * 256);
+    // SUSTAINED: the clock follows the power of the last milliseconds, so a variant is run back to back for ~60 ms
+    // (PROBE_REPS launches, default 400) and the second half is timed
+    const char* re = getenv("PROBE_REPS");
+    const int reps = re ? atoi(re) : 400;
+    for (int rep = 0; rep < reps; ++rep) {
+        if (rep == reps / 2) CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(probe_rega<FLAGS>, dim3(256), dim3(256), lds_bytes, 0, w, wslots, x, xslots, out, clk, tiles_per_wg, nstage, stagger);
+    }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms / (reps - reps / 2); }
+    CK(hipMemcpy(cb.data(), clk, 4 * 256 * 8, hipMemcpyDeviceToHost)); c = cb;
+    // over the 256 workgroups: mean / max cycles per tile, mean stage cycles, mean shader clock (cycles / 100 MHz wall ticks)
+    double tile = 0, tmax = 0, loop = 0, mhz = 0, wall = 0;
+    for (int i = 0; i < 256; ++i) {
+        tile += (double)c[4 * i + 1] / tiles_per_wg; loop += (double)c[4 * i] / tiles_per_wg;
+        if ((double)c[4 * i + 1] / tiles_per_wg > tmax) tmax = (double)c[4 * i + 1] / tiles_per_wg;
+        mhz += (double)c[4 * i + 3] / ((double)c[4 * i + 2] / 100.0); wall += (double)c[4 * i + 2] / 100.0;
+    }
+    tile /= 256; loop /= 256; mhz /= 256; wall /= 256;
+    printf("rega f=%-2d s=%-5d: %7.1f us per launch (in-kernel wall %6.1f us, %4.0f MHz); per tile %7.0f cycles (max %7.0f), main loop "
+           "%7.0f = %5.0f per stage (45 MFMAs = 1440)\n", FLAGS, stagger, best * 1e3, wall, mhz, tile, tmax, loop, loop / nstage);
+}
+
 template <bool WINO>
 static void run(const char* name, const u32x4* w, long wslots, const u32x4* x, long xslots, float* out,
                 long long* clk, int tiles_per_wg, int nstage) {
@@ -230,15 +505,17 @@ static void run(const char* name, const u32x4* w, long wslots, const u32x4* x, l
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     long long c[2] = {0, 0};
-    for (int rep = 0; rep < 6; ++rep) {
-        hipEventRecord(e0);
+    const char* re = getenv("PROBE_REPS");
+    const int reps = re ? atoi(re) : 400;
+    for (int rep = 0; rep < reps; ++rep) {
+        if (rep == reps / 2) CK(hipEventRecord(e0));
         hipLaunchKernelGGL(probe<WINO>, dim3(256), dim3(256), lds_bytes, 0, w, wslots, x, xslots, out, clk, tiles_per_wg, nstage);
-        hipEventRecord(e1);
-        CK(hipEventSynchronize(e1));
-        CK(hipGetLastError());
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        if (rep >= 2 && ms < best) { best = ms; hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost); }
     }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms / (reps - reps / 2); }
+    CK(hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost));
     printf("%-9s %2d tiles per CU x %2d stages: %8.1f us per launch; per tile %7.0f cycles, main loop %7.0f = %6.0f per stage "
            "(45 MFMAs = 1440)\n", name, tiles_per_wg, nstage, best * 1e3, (double)c[1] / tiles_per_wg,
            (double)c[0] / tiles_per_wg, (double)c[0] / tiles_per_wg / nstage);
@@ -253,7 +530,7 @@ int main() {
         v = (unsigned short)(((rand() & 1) << 15) | ((12 + (rand() & 3)) << 10) | (rand() & 0x3ff));
     }
     u32x4 *w, *x; float* out; long long* clk;
-    CK(hipMalloc(&w, wslots * 16)); CK(hipMalloc(&x, xslots * 16)); CK(hipMalloc(&out, 256L * 4 * 4 * 15 * 16 * 64 * 4)); CK(hipMalloc(&clk, 16));
+    CK(hipMalloc(&w, wslots * 16)); CK(hipMalloc(&x, xslots * 16)); CK(hipMalloc(&out, 256L * 4 * 4 * 15 * 16 * 64 * 4)); CK(hipMalloc(&clk, 4 * 256 * 8));
     CK(hipMemcpy(w, h.data(), wslots * 16, hipMemcpyHostToDevice));
     for (long off = 0; off < xslots * 16; off += (long)h.size() * 2)
         CK(hipMemcpy((char*)x + off, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -262,6 +539,33 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         if (!only || only[0] == 'd') run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
         if (!only || only[0] == 'w') run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
+        if (!only || only[0] == 'r' || only[0] == 's') {
+          if (only && only[0] == 's') {          // the short list: today's structure against the candidates, sustained
+            run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
+            run_rega<0>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<256>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1536>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<15>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
+          } else {
+            run_rega<0>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<16>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<256>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1536>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<258>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<6>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<2>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<4>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<8>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<3>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<15>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<0>(w, wslots, x, xslots, out, clk, 2, 60, 7000);
+          }
+        }
     }
     return 0;
 }
