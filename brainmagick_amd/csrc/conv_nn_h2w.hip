@@ -13,235 +13,101 @@
 // tensor / weight row), not element-wise: an element 2^-18 below its tensor's maximum keeps fewer than 22
 // bits; the reference's activations (BatchNorm'ed / clamped, bm/norm.py:332-333) span a few binades.
 //
-// Structure = conv_nn_x3w.hip (ONE workgroup of four wavefronts per CU, one wavefront per SIMD, wavefront
-// tile (32 MW) x 96 as MW x 3 MFMA accumulators, workgroup tile (64 MW) x 192, MW in {5, 4, 2}; weight slab
-// of stage s + 2 by LDS DMA, input window of the next chunk through registers, raw s_barrier with hand-counted
-// vmcnt), with two operand planes: stage = (16-channel chunk, tap) = 15 MW MFMAs per wavefront.
-// LDS: A [3 buffers][2 planes][2 groups][64 MW rows], X [2 buffers][2 planes][2 groups][256 columns] x 16 B.
+// Tile economy: ONE workgroup of four wavefronts per CU, one wavefront per SIMD, wavefront tile (32 MW) x 96 as
+// MW x 3 MFMA accumulators, workgroup tile (64 MW) x 192, MW in {5, 4, 2}; two operand planes: stage =
+// (16-channel chunk, tap) = 9 MW MFMAs per wavefront.  LDS: X [2 buffers][2 planes][2 groups][256 columns] x 16 B
+// (the weights do not pass through it, see below).
 // Packed weights: [g][chunk32][tap][plane][4 groups][Mpad] 16-byte slots (8 f16 channels), followed by the
 // per-row inverse scales [G][Mpad] fp32 (bm_pack_weights_h2).
-#include <cstdlib>
-#include <cstring>
-#include <utility>
-#include "conv_common.h"
+#include "conv_h2_common.h"
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4h __attribute__((ext_vector_type(4)));
-
-#define HBN 192           // columns of the workgroup tile (2 wavefront columns x 3 blocks)
-#define HXWP 256          // padded x-window width (>= 192 + 2 * 16; one column per thread)
-#define HXSLAB (2 * 2 * HXWP)     // 16-byte slots of one X buffer
-
-struct ConvH2Args {
-    ConvNNArgs c;
-    const float* x_amax;      // [BM_AMAX_SHARDS] shards whose maximum bounds |x| of the input tensor, device memory
-    const float* wscale;      // [G][Mpad] inverse row scales written by bm_pack_weights_h2
-    BmAmaxDst y_amax;         // where max |y_out| goes (bm_publish_amax): per-workgroup partials
-};
-
-// Power-of-two scale s with amax * s in [2^14, 2^15), and its exact inverse.  amax == 0 / subnormal / inf /
-// nan: s = 1 (non-finite operands then propagate through the split as inf / nan like in fp32).
-__host__ __device__ __forceinline__ void h2_scale_from_amax(float amax, float& s, float& inv) {
-    unsigned bits;
-    memcpy(&bits, &amax, 4);
-    const unsigned e = (bits >> 23) & 0xffu;
-    int se = 127;
-    if (e != 0u && e != 255u) {
-        se = 268 - (int)e;              // 127 + 14 - (e - 127)
-        se = se > 253 ? 253 : (se < 1 ? 1 : se);
-    }
-    const unsigned sb = (unsigned)se << 23, ib = (unsigned)(254 - se) << 23;
-    memcpy(&s, &sb, 4);
-    memcpy(&inv, &ib, 4);
-}
-
-// 8 fp32 values (already scaled) -> f16 planes hi, lo
-__device__ __forceinline__ void split8h(const float* f, float s, u32x4& hi, u32x4& lo) {
-    f16x8 h, l;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float xs = f[i] * s;
-        const _Float16 a = (_Float16)xs;
-        h[i] = a;
-        l[i] = (_Float16)(xs - (float)a);
-    }
-    hi = __builtin_bit_cast(u32x4, h);
-    lo = __builtin_bit_cast(u32x4, l);
-}
-
-// two fp32 values -> scaled f16 pairs: hi = f16(x * s), lo = f16(x * s - hi) (the product is exact, s is a power
-// of two; the difference is exact in fp32), written straight into the halves of the packed results: 4 VALU
-__device__ __forceinline__ void ch_split_pair(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(hi), "=&v"(lo)
-        : "v"(x0), "v"(x1), "v"(s));
-}
-
-template <int... I, class F>
-__device__ __forceinline__ void h2_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void h2_static_for(F&& f) {
-    h2_static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-__device__ __forceinline__ float ch_ld32(i32x4h rs, int voff) {
-    float v;
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rs) : "memory");
-    return v;
-}
-
-// Epilogue helpers: every accumulator block is addressed with compile-time indices (template recursion), so
-// the MW x 3 accumulators never leave the register file.
-template <int MW>
-struct H2Simple {
-    float* yb;
-    const float* rb;
-    int rowu, li, T;
-    int row0, M;              // first row of this lane (rowu + 4 h), rows of the layer
-    float bia[MW][16];
-};
-
-template <int MW, int NT, int MT, bool FULL>
-__device__ __forceinline__ float h2_simple_col(const H2Simple<MW>& e, f32x16 (&acc)[MW][3], float amx) {
-    if constexpr (MT < MW) {
-        // row of element r of this lane: e.row0 + MT * 32 + (r & 3) + 8 * (r >> 2); FULL: the tile lies inside M
-        float rv[16];
-        if (e.rb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = MT * 32 + (r & 3) + 8 * (r >> 2);
-                rv[r] = (FULL || e.row0 + dr < e.M) ? e.rb[(long)(e.rowu + dr) * e.T + e.li + NT * 32] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = MT * 32 + (r & 3) + 8 * (r >> 2);
-            float v = acc[MT][NT][r] + e.bia[MT][r];
-            if (e.rb) v += rv[r];
-            if (FULL || e.row0 + dr < e.M) {
-                amx = fmaxf(amx, fabsf(v));
-                e.yb[(long)(e.rowu + dr) * e.T + e.li + NT * 32] = v;
-            }
-        }
-        return h2_simple_col<MW, NT, MT + 1, FULL>(e, acc, amx);
-    }
-    return amx;
-}
-
-template <int MW, bool FULL>
-__device__ __forceinline__ float h2_simple_tile(const H2Simple<MW>& e, f32x16 (&acc)[MW][3], int col0, int T) {
-    float amx = 0.f;
-    if (col0 < T) amx = h2_simple_col<MW, 0, 0, FULL>(e, acc, amx);
-    if (col0 + 32 < T) amx = h2_simple_col<MW, 1, 0, FULL>(e, acc, amx);
-    if (col0 + 64 < T) amx = h2_simple_col<MW, 2, 0, FULL>(e, acc, amx);
-    return amx;
-}
-
-template <int MW, int I>
-__device__ __forceinline__ float h2_general_blocks(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* ep, int b,
-                                                   int m0, int rl_base, int col_base, float amx) {
-    if constexpr (I < MW * 3) {
-        constexpr int MT = I / 3, NT = I % 3;
-        float v[16];
-        float m = 0.f;
-        conv_ep_store_block(a, acc[MT][NT], ep, 64 * MW, b, m0, rl_base + MT * 32, col_base + NT * 32, v, &m);
-        return h2_general_blocks<MW, I + 1>(a, acc, ep, b, m0, rl_base, col_base, fmaxf(amx, m));
-    }
-    return amx;
-}
-
-// BatchNorm statistics of the tile (training-mode conv + BN layers, bm/models/common.py:119): per output row, sum and
-// sum of squares of y_pre = acc + bias over this wavefront's 96 columns, written as partial (tile, wavefront
-// column) of the channel-major `stats` [M][B * ntiles_n * 2][2] -- bm_bn_finalize_cm adds a channel's partials, one
-// contiguous run, in double.  Saves the
-// channel_stats pass over the 118 MB output.  Per row block: the lane's 3 column blocks are summed in registers,
-// then a halving butterfly over the 32 lanes of a half-wavefront (16 + 8 + 4 + 2 + 1 + 1 exchanges for 2 x 16
-// values instead of 5 x 32) leaves row q = 8 b4 + 4 b3 + 2 b2 + b1 (bk = bit k of the lane) in each lane.
-template <int MW>
-__device__ __forceinline__ void h2_tile_stats(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* epl /* lane's bias rows */,
-                                              float* stats_tile /* + (tile * 2 + wn) * 2 */, long row_stride /* floats between channels */,
-                                              int row0 /* first row of the lane's blocks */, int col0, int lane) {
-    const bool c0ok = col0 < a.T, c1ok = col0 + 32 < a.T, c2ok = col0 + 64 < a.T;
-    // wave-uniform: every column of the wavefront's 96 lies inside T (3 of the 4 wavefront tiles of a T = 360 segment)
-    const bool all_in = __builtin_amdgcn_readfirstlane(col0 - (lane & 31)) + 95 < a.T;
-    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-    h2_static_for<MW>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int mt = decltype(mc)::value;
-        float s1[16], s2[16];
-        if (all_in) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bias = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
-                const float v0 = acc[mt][0][r] + bias, v1 = acc[mt][1][r] + bias, v2 = acc[mt][2][r] + bias;
-                s1[r] = (v0 + v1) + v2;
-                s2[r] = fmaf(v0, v0, fmaf(v1, v1, v2 * v2));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bias = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
-                const float v0 = c0ok ? acc[mt][0][r] + bias : 0.f;
-                const float v1 = c1ok ? acc[mt][1][r] + bias : 0.f;
-                const float v2 = c2ok ? acc[mt][2][r] + bias : 0.f;
-                s1[r] = (v0 + v1) + v2;
-                s2[r] = fmaf(v0, v0, fmaf(v1, v1, v2 * v2));
-            }
-        }
-#define H2_FOLD(N_, BIT_, MASK_)                                                                  \
-        _Pragma("unroll") for (int i = 0; i < N_; ++i) {                                          \
-            const float k1 = BIT_ ? s1[i + N_] : s1[i], g1 = BIT_ ? s1[i] : s1[i + N_];            \
-            const float k2 = BIT_ ? s2[i + N_] : s2[i], g2 = BIT_ ? s2[i] : s2[i + N_];            \
-            s1[i] = k1 + __shfl_xor(g1, MASK_);                                                   \
-            s2[i] = k2 + __shfl_xor(g2, MASK_);                                                   \
-        }
-        H2_FOLD(8, b4, 16)
-        H2_FOLD(4, b3, 8)
-        H2_FOLD(2, b2, 4)
-        H2_FOLD(1, b1, 2)
-#undef H2_FOLD
-        s1[0] += __shfl_xor(s1[0], 1);
-        s2[0] += __shfl_xor(s2[0], 1);
-        // element index q of the lane's 16 -> row (q & 3) + 8 (q >> 2) of the block (C/D layout)
-        const int q = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
-        const int row = row0 + mt * 32 + (q & 3) + 8 * (q >> 2);
-        if (!(lane & 1) && row < a.M)
-            *reinterpret_cast<float2*>(stats_tile + (long)row * row_stride) = float2{s1[0], s2[0]};
-    });
-}
-
-template <int N, int MW>
-__device__ __forceinline__ void h2_barrier(f16x8 (&ah)[MW], f16x8 (&bh)[3]) {
-    if constexpr (MW == 5)
-        asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
-                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(ah[4]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
-                     : "n"(N) : "memory");
-    else if constexpr (MW == 4)
-        asm volatile("s_waitcnt vmcnt(%7) lgkmcnt(0)\n\ts_barrier"
-                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
-                     : "n"(N) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier"
-                     : "+v"(ah[0]), "+v"(ah[1]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2])
-                     : "n"(N) : "memory");
-}
-
+// ---------------------------------------------------------------------------------------------------------
+// Production main loop (round 6): the WEIGHT operand goes from L2 straight into MFMA fragment registers.
+//
+// The packed layout [chunk32][tap][plane][4 groups][Mpad] x 16 B already is fragment order -- lane (nl, h) of row
+// block mt wants the slot (group = 2 (c16 & 1) + h, row = m0 + wm 32 MW + 32 mt + nl) -- so a wavefront fetches a
+// fragment with ONE buffer_load_dwordx4 (two 512-byte runs), one stage ahead, into a second register set: no LDS-DMA
+// copy, no LDS write, no ds_read for A (the stage of conv_nn_h2d_kernel below: 5 copies + 10 reads per wavefront, and
+// a workgroup barrier per STAGE because the slab is shared).  LDS holds only the two X window buffers, and the
+// workgroup meets at one barrier per 16-channel chunk.  B fragments are double-buffered too (read during the
+// previous stage), so a stage is 3 MW NW MFMAs on operands that are all in registers when it starts:
+//     term 0: A.lo x B.hi,  term 1: A.hi x B.lo,  term 2: A.hi x B.hi.
+// What scripts/micro/wino_stage_probe.hip (arm "rega", profiles/r6_rega_probe.txt) measured on the way here:
+//   * the four wavefronts leave a barrier in lockstep; ten 1 KB loads each in consecutive MFMA slots hand the CU's
+//     one texture-address path twice what it takes per slot and the stage costs 1 760 cycles (LDS-DMA: 1 920) --
+//     ONE A load every FOURTH slot: 1 640, and the barrier costs nothing any more (it was absorbing that jitter);
+//   * the window's split two VALU at a time (a half pair per free slot, one LDS write per slot): 1 616;
+//   * a third A register set (two stages ahead), LDS flags instead of the barrier, window loads in two batches: no
+//     gain / slower, not built.
+// Every load is compiler-visible (raw buffer loads; hipcc counts vmcnt itself and waits at the first use).
+// Slots: the n-th MFMA of a stage is followed by at most one A load (n % 4 == 0) or by its share of the stage's
+// ordered item list (window loads / split halves / LDS writes / the barrier / the B reads of the next stage),
+// spread evenly over the other slots.
+// ---------------------------------------------------------------------------------------------------------
 #ifdef HG_TRACE
-// cycle trace of the stage pipeline (diagnostic builds only, scripts/build_trace_lib.sh): per workgroup and
-// wavefront, [tap j][segment] cycles summed over the stages, [3][7] = stage count
 __device__ unsigned ch_trace_buf[64 * 4 * 24];
-#define CH_T(I_) { __builtin_amdgcn_sched_barrier(0); tr[I_] = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 extern "C" int bm_debug_trace_read_conv(unsigned* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ch_trace_buf), sizeof(unsigned) * 64 * 4 * 24);
 }
-#else
-#define CH_T(I_)
 #endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t h2_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// the two halves of ch_split_pair as separate statements (2 VALU each): they sit in different MFMA slots
+__device__ __forceinline__ void ch_split_hi(float x0, float x1, float s, unsigned& hi) {
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(hi) : "v"(x0), "v"(x1), "v"(s));
+}
+__device__ __forceinline__ void ch_split_lo(float x0, float x1, float s, unsigned hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo) : "v"(hi), "v"(x0), "v"(x1), "v"(s));
+}
+
+// item kinds of a stage's list
+enum { H2R_NONE = 0, H2R_WLOAD, H2R_SPLIT, H2R_WRITE, H2R_BAR, H2R_BREAD };
+struct H2RItem { int kind, arg; };
+// Item i of the list of stage (KS, tap J); NB = 2 NW B reads.
+//   3 taps, J = 0: the 16 loads of the next chunk's window, the B reads of tap 1;
+//           J = 1: the B reads of tap 2 (IN FRONT of the barrier: they are the last reads of this chunk's buffer
+//                  pair before the next chunk overwrites the other buffer, and only a barrier behind them orders
+//                  them against that write), the window's 16 split halves with its 4 LDS writes (a group's two
+//                  behind its 8 halves), the barrier;      J = 2: the B reads of the next chunk's tap 0;
+//   1x1: split half, split half, then the two registers of the pair refilled with the window after next, x 8, the 4
+//        writes in between, the barrier, the B reads of the next chunk.
+template <int KS, int J, int NB>
+constexpr int h2r_nitems() {
+    if (KS == 1) return 32 + 4 + 1 + NB;
+    return J == 0 ? 16 + NB : J == 1 ? 16 + 4 + 1 + NB : NB;
+}
+template <int KS, int J, int NB>
+constexpr H2RItem h2r_item(int i) {
+    if (KS == 1) {
+        // per unit u: S(2u) S(2u+1) L(2u) L(2u+1); writes 0,1 behind unit 3, writes 2,3 behind unit 7
+        if (i < 16) return (i & 3) < 2 ? H2RItem{H2R_SPLIT, (i >> 2) * 2 + (i & 1)} : H2RItem{H2R_WLOAD, (i >> 2) * 2 + (i & 1)};
+        if (i < 18) return H2RItem{H2R_WRITE, i - 16};
+        if (i < 34) { const int k = i - 18; return (k & 3) < 2 ? H2RItem{H2R_SPLIT, 8 + (k >> 2) * 2 + (k & 1)} : H2RItem{H2R_WLOAD, 8 + (k >> 2) * 2 + (k & 1)}; }
+        if (i < 36) return H2RItem{H2R_WRITE, i - 34 + 2};
+        if (i == 36) return H2RItem{H2R_BAR, 0};
+        return H2RItem{H2R_BREAD, i - 37};
+    }
+    if (J == 0) return i < 16 ? H2RItem{H2R_WLOAD, i} : H2RItem{H2R_BREAD, i - 16};
+    if (J == 1) {
+        if (i < NB) return H2RItem{H2R_BREAD, i};
+        i -= NB;
+        if (i < 8) return H2RItem{H2R_SPLIT, i};
+        if (i < 10) return H2RItem{H2R_WRITE, i - 8};
+        if (i < 18) return H2RItem{H2R_SPLIT, i - 2};
+        if (i < 20) return H2RItem{H2R_WRITE, i - 18 + 2};
+        return H2RItem{H2R_BAR, 0};
+    }
+    return H2RItem{H2R_BREAD, i};
+}
 
 template <int KS, int MW>
 __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
@@ -251,10 +117,12 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
 #endif
     constexpr int NW = 3;
     constexpr int HBM = 64 * MW;                      // rows of the workgroup tile
-    constexpr int HASLAB = 2 * 2 * HBM;               // 16-byte slots of one A buffer
+    constexpr int TN = MW * NW, NS = 3 * TN;          // MFMAs of a term / of a stage
+    constexpr int NA = 2 * MW, NB = 2 * NW;           // A loads / B reads of a stage
+    constexpr int NF = NS - (NS + 3) / 4;             // free slots (n % 4 != 0)
+    static_assert(4 * (NA - 1) < NS, "the A loads of a stage need a slot each");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    u32x4* As = reinterpret_cast<u32x4*>(smem);       // [3 buffers][2 planes][2 groups][HBM]
-    u32x4* Xs = As + 3 * HASLAB;                      // [2 buffers][2 planes][2 groups][HXWP]
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem);       // [2 buffers][2 planes][2 groups][HXWP]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,23 +141,20 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     const int XW = HBN + 2 * halo;                    // <= 224
 
     const int g = a.widx ? a.widx[b] : 0;
-    const int nchunk32 = a.nchunk;
-    const int n16 = (a.Cin + 15) >> 4;                // channels past Cin read 0 through the bounds check
-    const int nstage = n16 * KS;
-    // packed weights in 16-byte slots: [g][chunk32][tap][plane][4][Mpad]
-    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (long)g * nchunk32 * KS * 8 * a.Mpad + m0 + lane;
+    const int n16 = 2 * a.nchunk;                     // 16-channel chunks, an even number; channels past Cin read 0
     float sx, sx_inv;
     h2_scale_from_amax(bm_amax_load(args.x_amax), sx, sx_inv);
 
-    // input window of this segment through a bounds-checked buffer descriptor: channels past Cin read 0
-    const unsigned long long xaddr = (unsigned long long)(a.x + (long)b * a.x_bstride);
-    i32x4h xr;
-    xr[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xaddr);
-    xr[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xaddr >> 32) & 0xffffu));
-    xr[2] = __builtin_amdgcn_readfirstlane(a.Cin * a.T * 4);
-    xr[3] = 0x00020000;
-    // thread `tid` stages window column tid (both 8-channel groups); columns outside [0, T) or past the
-    // window get an offset that stays out of range for every channel -> they read as 0 (conv zero padding)
+    // this group's packed planes [chunk32][tap][plane][4][Mpad] x 16 B behind one descriptor; a lane's slot inside a
+    // (stage, plane): (h Mpad + row) x 16, row block mt = an immediate (512 mt), stage and plane = the scalar offset
+    const long gslots = (long)a.nchunk * KS * 8 * a.Mpad;
+    const __amdgpu_buffer_rsrc_t wr = h2_rsrc(reinterpret_cast<const u32x4*>(a.wp) + (long)g * gslots, (unsigned)(gslots * 16));
+    const int wvoff = (h * a.Mpad + m0 + wm * (MW * 32) + nl) * 16;
+    const int pstride = 4 * a.Mpad * 16;              // bytes between the two planes of a stage
+    // input window of this segment through a bounds-checked descriptor: channels past Cin read 0; thread `tid`
+    // stages window column tid (both 8-channel groups); columns outside [0, T) or past the window get an offset
+    // that stays out of range for every channel -> they read as 0 (conv zero padding)
+    const __amdgpu_buffer_rsrc_t xr = h2_rsrc(a.x + (long)b * a.x_bstride, (unsigned)(a.Cin * a.T * 4));
     const int tcol = n0 - halo + tid;
     const int xoff0 = (tid < XW && tcol >= 0 && tcol < a.T) ? tcol * 4 : 0x40000000;
     const int crow = a.T * 4;
@@ -303,180 +168,113 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
     float xreg[16];
-    f16x8 af[2][MW], bf[2][NW];                       // operand fragments [plane 0 = hi, 1 = lo]
+    unsigned ph[8], pw[8];                            // the window being split: 8 pairs, planes hi / lo
+    f16x8 af[2][2][MW], bf[2][2][NW];                 // [register set][plane 0 = hi, 1 = lo][block]
 
-    // DMA of the A slab of stage S_ (clamped to the last stage) into A buffer BUF3_: 4 MW pieces of 64 slots,
-    // MW per wavefront
-#define DMA_A(S_, BUF3_)                                                                          \
-    {                                                                                             \
-        const int sc = (S_) < nstage ? (S_) : nstage - 1;                                         \
-        const int c16 = sc / KS, jj = sc - c16 * KS;                                              \
-        const u32x4* src = wg + ((long)((c16 >> 1) * KS + jj) * 8 + (c16 & 1) * 2) * a.Mpad;      \
-        _Pragma("unroll") for (int i = 0; i < MW; ++i) {                                          \
-            const int k = wave + 4 * i;                                                           \
-            const int run = k / MW, rb = k - run * MW;          /* run = plane * 2 + group */     \
-            const int plane = run >> 1, kg = run & 1;                                             \
-            __builtin_amdgcn_global_load_lds(                                                     \
-                (const void*)(src + (long)(plane * 4 + kg) * a.Mpad + rb * 64),                   \
-                (__attribute__((address_space(3))) void*)(As + (BUF3_) * HASLAB + run * HBM + rb * 64), 16, 0, 0); \
-        }                                                                                         \
-    }
-    // 16 channels x 1 column of the input window of chunk C16_ (zeros past the last chunk: offset out of range)
-#define LOAD_X(C16_)                                                                              \
-    {                                                                                             \
-        const int cb = (C16_) * 16 * crow + xoff0;                                                \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) xreg[r] = ch_ld32(xr, cb + r * crow);      \
-    }
-#define CH_WAIT_X(N_)                                                                             \
-    asm volatile("s_waitcnt vmcnt(%16)"                                                           \
-                 : "+v"(xreg[0]), "+v"(xreg[1]), "+v"(xreg[2]), "+v"(xreg[3]), "+v"(xreg[4]), "+v"(xreg[5]),  \
-                   "+v"(xreg[6]), "+v"(xreg[7]), "+v"(xreg[8]), "+v"(xreg[9]), "+v"(xreg[10]), "+v"(xreg[11]), \
-                   "+v"(xreg[12]), "+v"(xreg[13]), "+v"(xreg[14]), "+v"(xreg[15])                 \
-                 : "n"(N_) : "memory");
-#define STORE_X(BUF_)                                                                             \
-    {                                                                                             \
-        u32x4* xd = Xs + (BUF_) * HXSLAB + tid;                                                   \
-        _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                        \
-            u32x4 hi, lo;                                                                         \
-            split8h(xreg + 8 * kg, sx, hi, lo);                                                   \
-            xd[(0 * 2 + kg) * HXWP] = hi;                                                         \
-            xd[(1 * 2 + kg) * HXWP] = lo;                                                         \
-        }                                                                                         \
-    }
-    // single fragments of the stage in A buffer ABUF_ / X buffer XB_, tap J_ (plane 0 = hi, 1 = lo)
-#define FRAG_A(P_, ABUF_, MT_)                                                                    \
-    af[P_][MT_] = __builtin_bit_cast(f16x8, As[(ABUF_) * HASLAB + ((P_) * 2 + h) * HBM + wm * (MW * 32) + nl + (MT_) * 32]);
-#define FRAG_B(P_, XB_, J_, NT_)                                                                  \
-    bf[P_][NT_] = __builtin_bit_cast(f16x8, Xs[(XB_) * HXSLAB + ((P_) * 2 + h) * HXWP + wn * (NW * 32) + nl + (J_) * a.dil + (NT_) * 32]);
-    // "slab s + 1 landed" + workgroup barrier: N_ younger VMEM instructions may stay in flight.  The statement
-    // names the A.hi and B.hi fragments as read-write operands: the compiler moves register-only MFMAs freely
-    // across an asm statement ("memory" does not order them), and this pins the readers of B.hi before it.
-#define CH_BARRIER(N_) h2_barrier<N_, MW>(af[0], bf[0]);
-#define TERM(PA_, PB_)                                                                            \
-    _Pragma("unroll") for (int mt = 0; mt < MW; ++mt)                                             \
-        _Pragma("unroll") for (int nt = 0; nt < NW; ++nt)                                         \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA_][mt], bf[PB_][nt], acc[mt][nt], 0, 0, 0);
+    // A fragment K_ (lo plane first: term 0 uses it) of the stage at scalar byte offset SOFF_ into set SET_
+#define H2R_LOAD_A(SET_, K_, SOFF_)                                                                       \
+    af[SET_][1 - (K_) / MW][(K_) % MW] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(  \
+        wr, wvoff + ((K_) % MW) * 512, (SOFF_) + (1 - (K_) / MW) * pstride, 0));
+    // scalar byte offset of stage (C16_, J_): ((chunk32 KS + tap) 8 + 2 (c16 & 1)) Mpad slots
+#define H2R_SOFF(C16_, J_) (((((C16_) >> 1) * KS + (J_)) * 8 + ((C16_) & 1) * 2) * a.Mpad * 16)
+    // window value R_ (channel R_ of 16) of chunk C16_ for this thread's column
+#define H2R_LOAD_X(R_, CB_) xreg[R_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (CB_) + (R_) * crow, 0, 0));
+    const u32x4* xrd = Xs + h * HXWP + wn * (NW * 32) + nl;      // B fragment (plane p, block nt): + p 2 HXWP + 32 nt + tap shift
+    u32x4* xwr = Xs + tid;                                       // this thread's column: + (plane 2 + group) HXWP
 
-    // prologue: slabs 0 and 1, input window of chunk 0
-    DMA_A(0, 0)
-    DMA_A(1, 1)
-    LOAD_X(0)
-    CH_WAIT_X(0)
-    STORE_X(0)
-    if (KS == 1) LOAD_X(1)          // 1x1 convs: the window of chunk c + 2 is requested in stage c (see below)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // prologue: the window of chunk 0 (requested first: it comes from HBM), A of stage 0; split + written to X
+    // buffer 0; 1x1: the window of chunk 1 requested behind it; barrier; B of stage 0
+    h2_static_for<16>([&](auto rc) __attribute__((always_inline)) { H2R_LOAD_X(decltype(rc)::value, xoff0) });
+    h2_static_for<NA>([&](auto kc) __attribute__((always_inline)) { H2R_LOAD_A(0, decltype(kc)::value, 0) });
+    h2_static_for<8>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        ch_split_hi(xreg[2 * u], xreg[2 * u + 1], sx, ph[u]);
+        ch_split_lo(xreg[2 * u], xreg[2 * u + 1], sx, ph[u], pw[u]);
+    });
+    xwr[(0 * 2 + 0) * HXWP] = u32x4{ph[0], ph[1], ph[2], ph[3]};
+    xwr[(1 * 2 + 0) * HXWP] = u32x4{pw[0], pw[1], pw[2], pw[3]};
+    xwr[(0 * 2 + 1) * HXWP] = u32x4{ph[4], ph[5], ph[6], ph[7]};
+    xwr[(1 * 2 + 1) * HXWP] = u32x4{pw[4], pw[5], pw[6], pw[7]};
+    if (KS == 1) h2_static_for<16>([&](auto rc) __attribute__((always_inline)) { H2R_LOAD_X(decltype(rc)::value, 16 * crow + xoff0) });
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    h2_static_for<NB>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        bf[0][i / NW][i % NW] = __builtin_bit_cast(f16x8, xrd[(i / NW) * 2 * HXWP + (i % NW) * 32]);
+    });
 
-    // Stage s = (16-channel chunk c16, tap j), A buffer s % 3, X buffer c16 & 1; 3 MW NW MFMAs in three terms:
-    // hi*lo of the PREVIOUS stage (operands still in registers; zeros before the first stage), lo*hi, hi*hi, then
-    // the barrier.  One slot per MFMA, in source order (scheduling fence after each): a lone wavefront per SIMD
-    // issues one instruction every 8 cycles, so an MFMA (32 cycles) hides about 3 more, and anything issued in a
-    // burst -- 16 window loads, a read that is waited for at once -- leaves the matrix pipe idle (cycle trace:
-    // scripts/trace_conv.py).  Behind the MFMAs of a stage, at most a few instructions each:
-    //   term 0: the stage's first fragments (B.hi, A.lo);
-    //   term 1: the MW DMA copies of slab s + 2, the A.hi / B.lo fragments (term 2 / the next stage's term 0), and
-    //     3 taps, j == 0:      the 16 loads of the input window of chunk c16 + 1;
-    //     3 taps, j == KS - 1: that window, split pair by pair into X buffer (c16 + 1) & 1;
-    //     1x1:                 window c16 + 1 (requested in stage c16 - 1) split pair by pair, each pair's
-    //                          registers refilled with window c16 + 2 right behind.
-    // VMEM queue order of a stage: slab s + 2 (MW copies), then the window loads.  Counted waits: the window is
-    // consumed behind the copies of its stage (3 taps: younger are the copies of stages j = 1, 2; 1x1: this
-    // stage's copies); at the barrier slab s + 1 must have landed: younger are this stage's copies and the window
-    // loads issued since (3 taps: j = 0 and j = 1; 1x1: the window just waited for is older than nothing needed).
-#pragma unroll
-    for (int mt = 0; mt < MW; ++mt) af[0][mt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int nt = 0; nt < NW; ++nt) bf[1][nt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int TN = MW * NW;
-    constexpr int WS0 = TN + MW, WSN = 2 * TN - MW;   // slots behind the copies: [WS0, WS0 + WSN)
-    unsigned ph[4], pw[4];                            // one 8-channel group of the window being split
-    int s = 0;
-    int ab3 = 0;                                      // s % 3
 #ifdef HG_TRACE
     unsigned tr[8], tacc[3][8];
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) tacc[i][k] = 0;
     __builtin_amdgcn_sched_barrier(0);
     const unsigned t_loop0 = (unsigned)__builtin_readcyclecounter();
 #endif
-    for (int c16 = 0; c16 < n16; ++c16) {
-        const int xbuf = c16 & 1;
+    // stage (c16, tap J) on register set PAR: 3 MW NW MFMAs, the A loads and the B reads of the NEXT stage into set
+    // PAR ^ 1, the window work of its tap
+    auto stage = [&](int c16, auto jc, auto pc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value, par = decltype(pc)::value;
+        CH_T(0)
+        // next stage (clamped to the last one: its A is fetched again, harmlessly), its A offset, X buffer and tap
+        const bool last_chunk = c16 + 1 >= n16;
+        const int nc16 = (j == KS - 1 && !last_chunk) ? c16 + 1 : c16;
+        const int soff = (j == KS - 1) ? H2R_SOFF(nc16, last_chunk ? KS - 1 : 0) : H2R_SOFF(c16, j + 1);
+        const u32x4* xnext = xrd + ((j == KS - 1 ? c16 + 1 : c16) & 1) * HXSLAB + (j == KS - 1 ? 0 : (j + 1) * a.dil);
+        // the window this stage requests (3 taps: chunk c16 + 1, in tap 0; 1x1: chunk c16 + 2) / splits (chunk c16 + 1)
+        const int cb = (c16 + (KS == 1 ? 2 : 1)) * 16 * crow + xoff0;
+        u32x4* xw = xwr + ((c16 + 1) & 1) * HXSLAB;
+        h2_static_for<NS>([&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value;
+            constexpr int term = n / TN, w = n % TN, mt = w / NW, nt = w % NW;
+            constexpr int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[par][pa][mt], bf[par][pb][nt], acc[mt][nt], 0, 0, 0);
+            if constexpr (n % 4 == 0) {
+                if constexpr (n / 4 < NA) H2R_LOAD_A(par ^ 1, n / 4, soff)
+            } else {
+                constexpr int f = (n / 4) * 3 + n % 4 - 1;
+                constexpr int L = h2r_nitems<KS, j, NB>();
+                constexpr int i0 = (f * L + NF - 1) / NF, i1 = ((f + 1) * L + NF - 1) / NF;
+                h2_static_for<i1 - i0>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr H2RItem it = h2r_item<KS, j, NB>(i0 + decltype(ic)::value);
+                    if constexpr (it.kind == H2R_WLOAD) {
+                        H2R_LOAD_X(it.arg, cb)
+                    } else if constexpr (it.kind == H2R_SPLIT) {
+                        constexpr int u = it.arg / 2;
+                        if constexpr (it.arg % 2 == 0) ch_split_hi(xreg[2 * u], xreg[2 * u + 1], sx, ph[u]);
+                        else ch_split_lo(xreg[2 * u], xreg[2 * u + 1], sx, ph[u], pw[u]);
+                    } else if constexpr (it.kind == H2R_WRITE) {
+                        constexpr int kg = it.arg / 2, plane = it.arg % 2;
+                        if constexpr (plane == 0) xw[(0 * 2 + kg) * HXWP] = u32x4{ph[4 * kg], ph[4 * kg + 1], ph[4 * kg + 2], ph[4 * kg + 3]};
+                        else xw[(1 * 2 + kg) * HXWP] = u32x4{pw[4 * kg], pw[4 * kg + 1], pw[4 * kg + 2], pw[4 * kg + 3]};
+                    } else if constexpr (it.kind == H2R_BAR) {
+                        // every wavefront's columns of the next window are in LDS (and everybody is done reading the
+                        // buffer that the NEXT chunk's window will overwrite)
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    } else if constexpr (it.kind == H2R_BREAD) {
+                        constexpr int p = it.arg / NW, q = it.arg % NW;
+                        bf[par ^ 1][p][q] = __builtin_bit_cast(f16x8, xnext[p * 2 * HXWP + q * 32]);
+                    }
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        CH_T(4)
+#ifdef HG_TRACE
+        tacc[j][0] += tr[4] - tr[0]; tacc[j][7] += 1;
+#endif
+    };
+    // a chunk whose first stage runs on register set CP (3 taps: the sets alternate inside the chunk)
+    auto chunk = [&](int c16, auto cpc) __attribute__((always_inline)) {
+        constexpr int cp = decltype(cpc)::value;
         h2_static_for<KS>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            CH_T(0)
-            const int ab_next = ab3 == 2 ? 0 : ab3 + 1;
-            const int ab_next2 = ab_next == 2 ? 0 : ab_next + 1;
-            // source of slab s + 2 (clamped to the last stage) and of the window to request
-            const int sc = s + 2 < nstage ? s + 2 : nstage - 1;
-            const int dc16 = sc / KS, djj = sc - dc16 * KS;
-            const u32x4* dsrc = wg + ((long)((dc16 >> 1) * KS + djj) * 8 + (dc16 & 1) * 2) * a.Mpad;
-            const int cb = (c16 + (KS == 1 ? 2 : 1)) * 16 * crow + xoff0;
-            u32x4* xd = Xs + (xbuf ^ 1) * HXSLAB + tid;
-            h2_static_for<3 * TN>([&](auto nc) __attribute__((always_inline)) {
-                constexpr int n = decltype(nc)::value;
-                constexpr int term = n / TN, w = n % TN, mt = w / NW, nt = w % NW;
-                constexpr int pa = term == 1 ? 1 : 0, pb = term == 0 ? 1 : 0;
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[pa][mt], bf[pb][nt], acc[mt][nt], 0, 0, 0);
-                if constexpr (term == 0) {                                 // the stage's first fragments
-                    if constexpr (w < NW) FRAG_B(0, xbuf, j, w)
-                    else if constexpr (w < NW + MW) FRAG_A(1, ab3, w - NW)
-                }
-                // A.hi / B.lo (free once term 0 is issued) behind the copies: every wait on LDS data is an
-                // lgkmcnt(0), so no read may be issued right in front of the first MFMA of a term
-                if constexpr (n >= TN + MW && n < TN + 2 * MW) FRAG_A(0, ab3, n - TN - MW)
-                if constexpr (n >= TN + 2 * MW && n < TN + 2 * MW + NW) FRAG_B(1, xbuf, j, n - TN - 2 * MW)
-                if constexpr (term == 1 && w < MW) {                       // DMA piece w of slab s + 2
-                    constexpr int k4 = w;
-                    const int k = wave + 4 * k4;
-                    const int run = k / MW, rb = k - run * MW;             // run = plane * 2 + group
-                    __builtin_amdgcn_global_load_lds(
-                        (const void*)(dsrc + (long)((run >> 1) * 4 + (run & 1)) * a.Mpad + rb * 64),
-                        (__attribute__((address_space(3))) void*)(As + ab_next2 * HASLAB + run * HBM + rb * 64), 16, 0, 0);
-                }
-                if constexpr (n >= WS0) {
-                    constexpr int q = n - WS0;
-                    if constexpr (KS != 1 && j == 0) {                     // window loads, 16 over WSN slots
-                        constexpr int r0 = (q * 16 + WSN - 1) / WSN, r1 = ((q + 1) * 16 + WSN - 1) / WSN;
-                        h2_static_for<r1 - r0>([&](auto rc) __attribute__((always_inline)) {
-                            constexpr int r = r0 + decltype(rc)::value;
-                            if constexpr (r < 16) xreg[r] = ch_ld32(xr, cb + r * crow);
-                        });
-                    }
-                    if constexpr (KS == 1 || j == KS - 1) {                // split units, 8 over WSN slots
-                        if constexpr (q == 0) {
-                            if (KS == 1) CH_WAIT_X(MW) else CH_WAIT_X(2 * MW)
-                        }
-                        constexpr int u0 = (q * 8 + WSN - 1) / WSN, u1 = ((q + 1) * 8 + WSN - 1) / WSN;
-                        h2_static_for<u1 - u0>([&](auto uc) __attribute__((always_inline)) {
-                            constexpr int u = u0 + decltype(uc)::value;
-                            if constexpr (u < 8) {
-                                // the group of pairs 0-3 is written one unit late: not in front of term 2's wait
-                                if constexpr (u == 4) {
-                                    xd[(0 * 2 + 0) * HXWP] = u32x4{ph[0], ph[1], ph[2], ph[3]};
-                                    xd[(1 * 2 + 0) * HXWP] = u32x4{pw[0], pw[1], pw[2], pw[3]};
-                                }
-                                ch_split_pair(xreg[2 * u], xreg[2 * u + 1], sx, ph[u & 3], pw[u & 3]);
-                                if constexpr (u == 7) {
-                                    xd[(0 * 2 + 1) * HXWP] = u32x4{ph[0], ph[1], ph[2], ph[3]};
-                                    xd[(1 * 2 + 1) * HXWP] = u32x4{pw[0], pw[1], pw[2], pw[3]};
-                                }
-                                if constexpr (KS == 1) {
-                                    xreg[2 * u] = ch_ld32(xr, cb + (2 * u) * crow);
-                                    xreg[2 * u + 1] = ch_ld32(xr, cb + (2 * u + 1) * crow);
-                                }
-                            }
-                        });
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            CH_T(4)
-            if (KS == 1) CH_BARRIER(16 + MW) else if (j == KS - 1) CH_BARRIER(MW) else CH_BARRIER(16 + MW)
-            CH_T(5)
-#ifdef HG_TRACE
-            tacc[j][0] += tr[4] - tr[0]; tacc[j][4] += tr[5] - tr[4]; tacc[j][7] += 1;
-#endif
-            ab3 = ab_next;
-            ++s;
+            stage(c16, jc, std::integral_constant<int, (cp + j) & 1>{});
         });
+    };
+    // ONE loop over chunk pairs and nothing behind it (a peeled tail chunk made hipcc rotate the accumulators through
+    // copies and spill them in the 1x1 kernels): an odd chunk count runs one more chunk on zeros -- the packed planes
+    // are padded to whole 32-channel chunks, the window reads past Cin as 0
+    for (int c16 = 0; c16 < n16; c16 += 2) {
+        chunk(c16, std::integral_constant<int, 0>{});
+        chunk(c16 + 1, std::integral_constant<int, KS & 1>{});
     }
 #ifdef HG_TRACE
     __builtin_amdgcn_sched_barrier(0);
@@ -484,71 +282,14 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     if (blockIdx.x < 64 && lane == 0)
         for (int i = 0; i < 3; ++i) for (int k = 0; k < 8; ++k) ch_trace_buf[((blockIdx.x * 4 + wave) * 3 + i) * 8 + k] = tacc[i][k];
 #endif
-    TERM(0, 1)                                        // last stage
-    // drain the (clamped, unused) copies of the last stages before the LDS is re-used by the epilogue
+    // the (clamped, unused) loads of the last stage have landed and every wavefront is done with the X buffers
+    // before the LDS is re-used by the epilogue
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#undef DMA_A
-#undef LOAD_X
-#undef CH_WAIT_X
-#undef STORE_X
-#undef FRAG_A
-#undef FRAG_B
-#undef TERM
-#undef CH_BARRIER
+#undef H2R_LOAD_A
+#undef H2R_SOFF
+#undef H2R_LOAD_X
 
-    // epilogue: inverse scales (exact powers of two), bias, optional pre-activation store, per-channel affine,
-    // activation, residual.  One literal-indexed expansion per accumulator block keeps the accumulators in
-    // registers.  ep[3 HBM .. 4 HBM) = per-row accumulator factor = inverse weight-row scale x inverse x scale.
-    float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
-    conv_ep_stage_params(a, ep, HBM, m0, tid, 256, b);
-    {
-        const float* ws = args.wscale + (long)g * a.Mpad + m0;
-        for (int i = tid; i < HBM; i += 256) ep[3 * HBM + i] = ws[i] * sx_inv;
-    }
-    __syncthreads();
-    {
-        const float* fl = ep + 3 * HBM + wm * (MW * 32) + 4 * h;
-#pragma unroll
-        for (int mt = 0; mt < MW; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float f = fl[mt * 32 + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-                for (int nt = 0; nt < NW; ++nt) acc[mt][nt][r] *= f;
-            }
-    }
-    // Common case (every wide launch of the training step): one output tensor, no affine / activation.  Row
-    // addresses are wave-uniform bases + one per-lane offset + an immediate per column block, the row biases are
-    // read once: ~3 VALU issue slots per stored element instead of ~10.  Tiles that straddle M (270-channel
-    // layers in 320-row tiles) take the same path with a row predicate.
-    if (a.stats)            // training-mode BatchNorm layers: the host allows it only with y_pre alone (simple path)
-        h2_tile_stats<MW>(a, acc, ep + wm * (MW * 32) + 4 * h,
-                          a.stats + (long)((b * a.ntiles_n + ntile) * 2 + wn) * 2, (long)a.B * a.ntiles_n * 4,
-                          m0 + wm * (MW * 32) + 4 * h, n0 + wn * (NW * 32) + nl, lane);
-    const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE;
-    if (simple) {
-        H2Simple<MW> e;
-        e.yb = (a.y_pre ? a.y_pre : a.y_out) + (long)b * a.y_bstride;
-        e.rb = (a.y_out && a.res) ? a.res + (long)b * a.res_bstride : nullptr;
-        e.rowu = m0 + wm * (MW * 32);                       // wave-uniform first row
-        e.li = 4 * h * a.T + n0 + wn * (NW * 32) + nl;      // per-lane element offset inside a row block
-        e.T = a.T;
-        e.row0 = e.rowu + 4 * h;
-        e.M = a.M;
-        const float* epl = ep + wm * (MW * 32) + 4 * h;
-#pragma unroll
-        for (int mt = 0; mt < MW; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) e.bia[mt][r] = epl[mt * 32 + (r & 3) + 8 * (r >> 2)];
-        const int col0 = n0 + wn * (NW * 32) + nl;
-        const float amx = m0 + HBM <= a.M ? h2_simple_tile<MW, true>(e, acc, col0, a.T)
-                                          : h2_simple_tile<MW, false>(e, acc, col0, a.T);
-        if (a.y_out) bm_publish_amax(amx, args.y_amax, smem + 4 * HBM);
-    } else {
-        const float amx = h2_general_blocks<MW, 0>(a, acc, ep, b, m0, wm * (MW * 32) + 4 * h,
-                                                   n0 + wn * (NW * 32) + nl, 0.f);
-        bm_publish_amax(amx, args.y_amax, smem + 4 * HBM);
-    }
+    h2_tile_epilogue<MW>(args, acc, smem, b, g, m0, n0, ntile, sx_inv, tid, lane, wm, wn, nl, h);
 #ifdef HG_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile's stores have left the CU
     if (blockIdx.x < 64 && lane == 0) {
@@ -813,8 +554,11 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
     size_t lds = (size_t)(3 * 2 * 2 * HBM + 2 * HXSLAB) * 16;
     const size_t lds_ep = (size_t)(4 * HBM + 4) * sizeof(float);
     if (lds < lds_ep) lds = lds_ep;
+    // BM_CONV_LDSDMA=1: the round-2..5 main loop (weight slabs by LDS-DMA, a barrier per stage; conv_nn_h2d.hip), for A/B runs
+    static const bool ldsdma = [] { const char* e = getenv("BM_CONV_LDSDMA"); return e && e[0] == '1'; }();
+    if (!ldsdma) lds = (size_t)(2 * HXSLAB) * 16 > lds_ep ? (size_t)(2 * HXSLAB) * 16 : lds_ep;
     static bool attr_set = false;
-    if (!attr_set) {
+    if (!ldsdma && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_h2w_kernel<KS, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "conv_nn_h2w: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -828,7 +572,10 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
     const bool publish = y_amax_out && args.y_amax.ws && nblocks <= BM_AMAX_WS;
     float* ws = args.y_amax.ws;
     if (!publish) args.y_amax = BmAmaxDst{nullptr};
-    hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
+    if (ldsdma) {
+        if (int rc = bm_launch_conv_nn_h2d(args, KS, MW, lds, (unsigned)nblocks, stream)) return rc;
+    } else
+        hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
     if (int rc = bm_check_launch("conv_nn_h2w")) return rc;
     if (publish) return bm_amax_done(args.y_amax, (int)nblocks, y_amax_out, stream);
     if (y_amax_out && ws)           // grid larger than the workspace: a plain pass over the output instead
