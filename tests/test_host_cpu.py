@@ -211,7 +211,7 @@ def test_data_parallel_exchange_world2_gloo(tmp_path):
         assert p.returncode == 0 and f"WORKER_OK {r}" in out, out
 
 
-_WIDE = ("gemm_nt_h2w.hip", "conv_nn_h2w.hip")
+_WIDE = ("gemm_nt_h2w.hip", "conv_nn_h2w.hip", "conv_nn_h2d.hip")
 _asm_cache = {}
 
 
@@ -253,20 +253,45 @@ def test_wide_kernels_do_not_spill():
 
 
 def test_hand_issued_loads_are_not_touched_before_their_wait():
-    """conv_nn_h2w issues the input-window loads through inline asm with hand-counted waits (a
-    compiler-visible load next to the LDS-DMA weight copies would drain the DMA queue at every use).  hipcc may
-    copy or re-use an asm load's destination register while the load is still in flight; scripts/audit_asm_loads.py
-    checks on the generated ISA that it does not.  (gemm_nt_h2w uses compiler-visible loads for exactly that
-    reason: there the allocator did copy an in-flight staging set.)"""
+    """conv_nn_h2d (the LDS-DMA main loop kept for A/B runs) issues the input-window loads through inline asm with
+    hand-counted waits (a compiler-visible load next to the LDS-DMA weight copies would drain the DMA queue at every
+    use).  hipcc may copy or re-use an asm load's destination register while the load is still in flight;
+    scripts/audit_asm_loads.py checks on the generated ISA that it does not.  (gemm_nt_h2w and, since round 6, the
+    production conv_nn_h2w use compiler-visible loads only: there is no LDS-DMA next to them any more.)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("audit_asm_loads", ROOT / "scripts" / "audit_asm_loads.py")
     audit = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(audit)
     asm = _wide_kernel_asm()
-    for name in ("conv_nn_h2w.hip",):
+    for name in ("conv_nn_h2d.hip",):
         violations = audit.audit_text(asm[name])
         assert not violations, (name, violations[:5])
-    assert "buffer_load" not in "".join(l for l in asm["gemm_nt_h2w.hip"].splitlines() if "ASMSTART" in l)
+    for name in ("gemm_nt_h2w.hip", "conv_nn_h2w.hip"):
+        in_asm, hidden = False, []
+        for line in asm[name].splitlines():
+            if "ASMSTART" in line:
+                in_asm = True
+            elif "ASMEND" in line:
+                in_asm = False
+            elif in_asm and ("buffer_load" in line or "global_load" in line):
+                hidden.append(line.strip())
+        assert not hidden, (name, hidden[:3])
+
+
+def test_wide_conv_accumulates_in_place():
+    """The production conv keeps its MW x 3 accumulator blocks in the same AGPRs for the whole tile: every MFMA of
+    the main loop writes the block it reads.  (A peeled tail chunk behind the chunk-pair loop once made hipcc rotate
+    the blocks through copies -- 200 v_accvgpr moves and 88 scratch accesses per loop trip in the 1x1 kernels.)"""
+    import re
+    asm = _wide_kernel_asm()["conv_nn_h2w.hip"]
+    kernels = re.findall(r"^(_Z\d+conv_nn_h2w_kernel\w+):.*?^\.Lfunc_end", asm, flags=re.M | re.S)
+    bodies = re.findall(r"^_Z\d+conv_nn_h2w_kernel\w+:(.*?)^\.Lfunc_end", asm, flags=re.M | re.S)
+    assert len(kernels) == 6 and len(bodies) == 6, kernels
+    for name, body in zip(kernels, bodies):
+        mfmas = re.findall(r"v_mfma_f32_32x32x16_f16 (a\[\d+:\d+\]), [^,]+, [^,]+, (\S+)", body)
+        assert len(mfmas) >= 36, (name, len(mfmas))      # 1x1, MW = 2: two stages of 18
+        moved = [m for m in mfmas if m[0] != m[1]]
+        assert not moved, (name, moved[:3])
 
 
 def test_deep_mel_known_answer_of_the_reference():
