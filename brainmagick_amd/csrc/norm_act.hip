@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // only makes it slower.  The sums are folded in split order by every workgroup alike: deterministic.
 // ------------------------------------------------------------------------------------------------
 #define FUSED_MAXIT 10            // float4 positions per thread held between the phases (80 VGPRs; 4 workgroups per CU)
-#define FUSED_POLL_LIMIT 192u
+#define FUSED_POLL_LIMIT 64u      // x s_sleep(64) ~ 0.13 ms: partners normally publish within ~10 us (they are dispatched together)
 #define FUSED_SENTINEL 0xffffffffffffffffull
 
 // dz and xhat of one element, and the running sums, in ONE place: the keeping pass and the fallback pass must round alike
@@ -374,6 +374,10 @@ __device__ __forceinline__ void fused_elem(float dv, float yv, float sc, float s
     s0 += dz;
     s1 = fmaf(dz, xh, s1);
 }
+
+// how many workgroups gave up on a partner and computed its sums themselves since the library was loaded (a slow path,
+// never a wrong one): bm_act_bn_bwd_fused_fallbacks() reads it -- bench.py and the tests report it
+__device__ unsigned long long bn_fused_fallbacks = 0ull;
 
 template <int MAXIT>
 __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(256, 4) void bn_bwd_fused_kernel(
     // partners that did not publish in time (never under a sane dispatcher): their sums, computed here, bit-identically
     const unsigned missing = missing_sh;
     if (missing) {
+        if (threadIdx.x == 0) atomicAdd(&bn_fused_fallbacks, 1ull);
         for (int k = 0; k < nsplit; ++k) {
             if (!((missing >> k) & 1u)) continue;
             const int kb0 = (int)((long)B * k / nsplit), kb1 = (int)((long)B * (k + 1) / nsplit);
@@ -543,6 +548,12 @@ extern "C" int bm_act_bn_bwd_set_poll_limit(int polls) {
     const int prev = (int)g_fused_poll_limit;
     g_fused_poll_limit = polls < 0 ? FUSED_POLL_LIMIT : (unsigned)polls;
     return prev;
+}
+// debug counter (synchronises the device): workgroups of the one-pass kernel that took the self-sufficient fallback
+extern "C" long bm_act_bn_bwd_fused_fallbacks() {
+    unsigned long long n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(bn_fused_fallbacks), sizeof(n)) != hipSuccess) return -1;
+    return (long)n;
 }
 extern "C" int bm_act_bn_bwd_set_fused(int mode) {
     const int prev = g_bn_bwd_fused;

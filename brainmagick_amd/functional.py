@@ -24,9 +24,12 @@ _arange_cache = {}
 
 def _arange_i32(n: int, device, repeat: int = 1) -> torch.Tensor:
     """torch.arange(n, int32).repeat(repeat) on `device`, built once per (n, repeat, device): the composed front end
-    asked for four of them per step (four tiny launches each time); they are constants."""
-    # (keyed by the stream as well: a tensor built on one stream is only ordered against kernels of that stream)
-    key = (n, repeat, device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    asked for four of them per step (four tiny launches each time); they are constants.
+
+    READ-ONLY: the returned tensor is shared by every caller (kernel index arguments, autograd contexts); an in-place
+    write by a consumer would corrupt every later step.  It is complete before it is handed out (one synchronisation
+    when it is built), so it is valid on any stream."""
+    key = (n, repeat, device.type, device.index)
     t = _arange_cache.get(key)
     if t is None:
         if len(_arange_cache) > 64:
@@ -34,6 +37,8 @@ def _arange_i32(n: int, device, repeat: int = 1) -> torch.Tensor:
         t = torch.arange(n, dtype=torch.int32, device=device)
         if repeat != 1:
             t = t.repeat(repeat)
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()
         _arange_cache[key] = t
     return t
 

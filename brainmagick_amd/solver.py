@@ -351,8 +351,8 @@ class Solver:
 
     def _snapshot(self):
         """What a deferred assert must be able to put back (``_rollback``): references to the last good batch and the
-        negatives pool, the state of the pool's generator, and ONE small device copy of the flat BatchNorm buffer
-        bucket (6 400 floats for the paper model)."""
+        negatives pool, the state of the pool's generator, ONE small device copy of the flat BatchNorm buffer
+        bucket (6 400 floats for the paper model) and one of the BatchNorm batch counters."""
         if not self.check_finite:
             return None
         flat = self._buffers.flat
@@ -362,7 +362,12 @@ class Solver:
             self._buffers_undo.copy_(flat)
         gen = self.negative_generator.get_state() if (self.n_negatives is not None and
                                                       self.negative_generator is not None) else None
-        return self._last_batch, dict(self.negative_pool), gen
+        # BatchNorm batch counters: copied, not decremented on the way back -- a module that did not run in train mode
+        # this step (unused branch, an eval-mode feature model) must keep its count
+        counters = [mod.num_batches_tracked for model in self._all_models() for mod in model.modules()
+                    if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.num_batches_tracked is not None]
+        counts = torch.stack(counters).clone() if counters else None
+        return self._last_batch, dict(self.negative_pool), gen, counters, counts
 
     def _rollback(self, undo) -> None:
         """A deferred assert fired after the forward pass of ``train_step``: restore what the reference, which asserts
@@ -374,15 +379,23 @@ class Solver:
         which would poison its running estimates for good; README "Deviations".)"""
         if undo is None:
             return
-        self._last_batch, self.negative_pool, gen = undo
+        rejected = self._last_batch
+        self._last_batch, self.negative_pool, gen, counters, counts = undo
         if gen is not None:
             self.negative_generator.set_state(gen)
         if self._buffers.flat is not None:
             self._buffers.flat.copy_(self._buffers_undo)
-        for model in self._all_models():
-            for mod in model.modules():
-                if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.num_batches_tracked is not None:
-                    mod.num_batches_tracked.sub_(1)
+        if counts is not None:
+            for counter, value in zip(counters, counts.unbind(0)):
+                counter.copy_(value)
+        # a prefetch made between the loss and this assert may have prepared the poisoned batch as the stand-in of a
+        # fully rejected next batch (prefetch() substitutes `_last_batch`, which was the rejected one at that point):
+        # a caller that catches the assert and goes on must not train on it
+        pre = self._prefetched
+        if pre is not None and pre[2] is not pre[0] and pre[2] is rejected and rejected is not self._last_batch:
+            if self._gather is not None:
+                self._gather.cancel()
+            self._prefetched = None
 
     # -- checkpoint (bm/solver.py:64,115-117: flashy's commit writes the registered state on rank 0) --------
     def state_dict(self) -> dict:

@@ -187,6 +187,7 @@ int bm_bwd_nsplit(int B);
 long bm_act_bn_bwd_workspace_bytes(int B, int C);
 int bm_act_bn_bwd_set_fused(int mode);                    /* 0: two passes; 1: one pass (-1: default = 1 unless BM_BN_BWD_FUSED=0); returns the previous setting */
 int bm_act_bn_bwd_set_poll_limit(int polls);              /* test hook: polls before a workgroup computes its partners' sums itself (-1: default) */
+long bm_act_bn_bwd_fused_fallbacks(void);                 /* debug counter (synchronises): workgroups of the one-pass kernel that gave up on a partner and computed its sums themselves */
 int bm_act_bn_bwd_fused_covers(int B, int C, int T);      /* 1: train-mode BatchNorm backward runs as ONE pass (slab in registers) */
 int bm_act_bn_bwd(const float* dout, const float* y, const float* scale, const float* shift,
                   const float* mean, const float* invstd, int bn_train, float* dy, float* dgamma,

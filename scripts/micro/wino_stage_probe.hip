@@ -539,8 +539,17 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         if (!only || only[0] == 'd') run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
         if (!only || only[0] == 'w') run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
-        if (!only || only[0] == 'r' || only[0] == 's') {
-          if (only && only[0] == 's') {          // the short list: today's structure against the candidates, sustained
+        if (!only || only[0] == 'r' || only[0] == 's' || only[0] == 'e') {
+          if (only && only[0] == 'e') {          // where the wall time (= energy, the chip is power-limited) of the kept form goes
+            run_rega<1280>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1281>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1282>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1288>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1284>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1283>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<15>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+          } else if (only && only[0] == 's') {          // the short list: today's structure against the candidates, sustained
             run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
             run_rega<0>(w, wslots, x, xslots, out, clk, 2, 60, 0);
             run_rega<256>(w, wslots, x, xslots, out, clk, 2, 60, 0);

@@ -386,9 +386,89 @@ def mne_layout_fixture(common):
             "ch_names": np.array(ch_names), "positions": positions.numpy().copy()}
 
 
+def wide_kernels_fixture(sc, common, losses):
+    """The paper architecture at the smallest size the headline wide f16x2 kernels take (hidden 256, depth 4, 64
+    sensors, T = 192, batch 8), two training steps of the live reference.  Parameters (1.6 M) and inputs are rebuilt
+    from the seed by the consumer (tests/helpers.py: wide_inputs, randomize_batchnorm); stored: digests of both, the
+    forward output, the losses of both steps, and per parameter the gradient norm, 64 sampled gradient elements and the
+    same 64 elements of the parameter after the two Adam steps."""
+    sys.path.insert(0, str(HERE.parent))
+    import helpers as Hh
+    d = Hh.WIDE_DIMS
+    sb, candidates, ban_center, gen = Hh.wide_inputs()
+    torch.manual_seed(d["seed"])
+    model = sc.SimpleConv(in_channels={"meg": d["C"]}, out_channels=d["F"], hidden={"meg": d["hidden"]},
+                          n_subjects=d["S"], **Hh.WIDE_CFG)
+    Hh.randomize_batchnorm(model, gen)
+    # the replacement classes must rebuild the very same parameters from the seed
+    from brainmagick_amd.models import SimpleConv as HipSimpleConv
+    torch.manual_seed(d["seed"])
+    gen2 = Hh.wide_inputs()[3]
+    mine = HipSimpleConv(in_channels={"meg": d["C"]}, out_channels=d["F"], hidden={"meg": d["hidden"]},
+                         n_subjects=d["S"], **Hh.WIDE_CFG)
+    Hh.randomize_batchnorm(mine, gen2)
+    sd_ref, sd_mine = model.state_dict(), mine.state_dict()
+    assert list(sd_ref) == list(sd_mine)
+    for k in sd_ref:
+        assert torch.equal(sd_ref[k], sd_mine[k]), k
+    loss_mod = losses.ClipLoss()
+    optim = torch.optim.Adam(model.parameters(), lr=3e-4, betas=(0.9, 0.999))
+    model.train(True)
+    loss_mod.train(True)
+    batch = _Batch(sb)
+    common.PositionGetter.get_positions = lambda self, b: b._positions.clone()
+    real_rand = torch.rand
+
+    def fake_rand(*a, **k):
+        if a == (2,):
+            return ban_center.clone()
+        return real_rand(*a, **k)
+
+    out = {"meta": json.dumps(dict(dims=d, cfg=Hh.WIDE_CFG, n_steps=2, torch=torch.__version__,
+                                   n_params=sum(p.numel() for p in model.parameters())))}
+    for k, v in model.state_dict().items():
+        out[f"sd0_digest/{k}"] = Hh.tensor_digest(v)
+    out["in_digest/meg"] = Hh.tensor_digest(sb.meg)
+    out["in_digest/candidates"] = Hh.tensor_digest(candidates)
+    out["in_digest/positions"] = Hh.tensor_digest(batch._positions)
+    out["in/ban_center"] = ban_center.numpy().copy()
+    common.torch.rand = fake_rand
+    try:
+        seen = []
+        for step in range(2):
+            mask = torch.ones(len(sb.meg), 1, d["T"], dtype=torch.bool)
+            estimate = model({"meg": sb.meg.clone()}, batch)
+            loss = loss_mod(estimate, candidates, mask)
+            optim.zero_grad()
+            loss.backward()
+            if step == 0:
+                out["out/estimate"] = estimate.detach().numpy().copy()
+                for k, p in model.named_parameters():
+                    g = p.grad.detach().flatten()
+                    idx = Hh.sample_indices(g.numel())
+                    out[f"grad_norm/{k}"] = np.array(float(g.double().norm()))
+                    out[f"grad_max/{k}"] = np.array(float(g.abs().max()))
+                    out[f"grad_sample/{k}"] = g[idx].numpy().copy()
+            optim.step()
+            seen.append(float(loss))
+    finally:
+        common.torch.rand = real_rand
+    out["out/losses"] = np.asarray(seen, dtype=np.float64)
+    for k, p in model.named_parameters():
+        out[f"sd1_sample/{k}"] = p.detach().flatten()[Hh.sample_indices(p.numel())].numpy().copy()
+    return out
+
+
 def main(only=()):
     """`python make_golden.py` regenerates everything; `python make_golden.py <variant> ...` only those models."""
     sc, common, losses = load_reference()
+    only = tuple(only)
+    if only == ("wide_kernels_train",) or not only:
+        out = wide_kernels_fixture(sc, common, losses)
+        np.savez_compressed(HERE / "wide_kernels_train.npz", **out)
+        print(f"wide_kernels_train: losses={out['out/losses']}")
+        if only:
+            return
     if only:
         for name in only:
             out = run_variant(name, VARIANTS[name], sc, common, losses)

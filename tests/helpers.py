@@ -44,3 +44,56 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     if denom == 0:
         return a.norm().item()
     return (a - b).norm().item() / denom
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The "wide kernels" fixture (tests/golden/wide_kernels_train.npz): the smallest model whose convs and weight gradients
+# run in the headline wide f16x2 kernels (T > 128, M >= 96), held to the LIVE reference directly.  Its 1.6 M
+# parameters and its inputs are not stored: both sides rebuild them from the seed (same constructor RNG order, same
+# synthetic batch generator) and the fixture keeps digests to prove that they did.
+# ---------------------------------------------------------------------------------------------------------------
+WIDE_DIMS = dict(B=8, C=64, T=192, F=32, S=4, hidden=256, seed=4077)
+WIDE_CFG = dict(depth=4, kernel_size=3, dilation_growth=2, dilation_period=5, batch_norm=True, skip=True, gelu=True,
+                glu=2, glu_context=1, glu_glu=True, complex_out=True, merger=True, merger_pos_dim=288,
+                merger_channels=256, merger_dropout=0.2, initial_linear=256, initial_depth=1, subject_layers=True,
+                subject_layers_dim="input", subject_dim=0)
+
+
+def wide_inputs():
+    """(synthetic batch, candidates, ban centre, generator positioned behind them) of the wide fixture."""
+    from brainmagick_amd.synthetic import make_batch
+    d = WIDE_DIMS
+    sb = make_batch(d["B"], d["C"], d["T"], d["F"], d["S"], seed=d["seed"], n_layouts=2)
+    gen = torch.Generator().manual_seed(d["seed"] + 1)
+    ban_center = torch.rand(2, generator=gen)
+    return sb, sb.features, ban_center, gen
+
+
+def randomize_batchnorm(model, gen):
+    """Non-trivial BatchNorm affine parameters / running statistics, drawn in module order from `gen`."""
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.5, 1.5, generator=gen)
+                mod.bias.uniform_(-0.3, 0.3, generator=gen)
+                mod.running_mean.uniform_(-0.2, 0.2, generator=gen)
+                mod.running_var.uniform_(0.5, 1.5, generator=gen)
+
+
+def tensor_digest(t: torch.Tensor):
+    """(sum, sum of squares, xor of the bit patterns) -- equal digests of two fp32 tensors built by the same code from
+    the same seed mean identical tensors for every practical purpose."""
+    t = t.detach().cpu().contiguous()
+    if t.is_floating_point():
+        bits = t.float().view(torch.int32).flatten()
+        x = 0
+        for chunk in bits.split(1 << 20):
+            x ^= int(np.bitwise_xor.reduce(chunk.numpy().view(np.uint32))) if chunk.numel() else 0
+        d = t.double()
+        return np.array([float(d.sum()), float((d * d).sum()), float(x)], dtype=np.float64)
+    return np.array([float(t.double().sum()), 0.0, 0.0], dtype=np.float64)
+
+
+def sample_indices(numel: int, n: int = 64, seed: int = 0):
+    gen = torch.Generator().manual_seed(seed + numel)
+    return torch.randint(0, numel, (min(n, numel),), generator=gen)

@@ -141,14 +141,16 @@ def test_subject_layers_kernels(H):
     assert torch.count_nonzero(dW[1]) == 0
 
 
+@pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("B,C,T", [(256, 320, 360),      # the production shape: 10 splits of <= 26 segments per channel
                                    (173, 320, 360),      # ragged batch: splits of 17 / 18 segments
                                    (37, 64, 192),        # one slab shorter than a workgroup's first trip
                                    (6, 40, 360), (1, 8, 4), (64, 1500, 48)])
-def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
+def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T, train):
     """bm_act_bn_bwd in train mode runs as ONE pass when T % 4 == 0 and a split's slab fits the registers
     (bn_bwd_fused_kernel: the workgroups of a channel exchange their partial sums inside the launch): same results as
-    the two-pass kernels (to summation order), the fp64 formula, and bit-identical from run to run."""
+    the two-pass kernels (to summation order), the fp64 formula, and bit-identical from run to run.  ``train=False``:
+    eval-mode BatchNorm with affine gradients takes the same kernel (the sums only feed dgamma / dbeta)."""
     from brainmagick_amd._lib import lib
     g = _gen(B + C + T)
     y = torch.randn(B, C, T, generator=g) * 1.5 + 0.3
@@ -167,7 +169,7 @@ def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
         try:
             if mode:
                 assert lib().bm_act_bn_bwd_fused_covers(B, C, T) == 1
-            dy, dgamma, dbeta, dbias = H.act_bn_bwd(*args, True, H.ACT_GELU, want_affine_grads=True)
+            dy, dgamma, dbeta, dbias = H.act_bn_bwd(*args, train, H.ACT_GELU, want_affine_grads=True)
             amax, rows = H.amax(dy).clone(), H.row_amax_of(dy)
             torch.cuda.synchronize()
             return dy, dgamma, dbeta, dbias, amax, (rows.clone() if rows is not None else None)
@@ -181,6 +183,9 @@ def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
     xh = (yd - mean[None, :, None]) * invstd[None, :, None]
     n = B * T
     ref = scale[None, :, None] * (dz - dz.sum((0, 2), keepdim=True) / n - xh * (dz * xh).sum((0, 2), keepdim=True) / n)
+    if not train:
+        ref = scale[None, :, None] * dz
+    fallbacks0 = lib().bm_act_bn_bwd_fused_fallbacks()
     results = [("two-pass", two)]
     for mode in (1,):
         one, again = run(mode), run(mode)
@@ -188,11 +193,14 @@ def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
             assert a is None or torch.equal(a, b)                     # deterministic
         results.append((f"one-pass mode {mode}", one))
         # partners that never publish in time: every workgroup computes the other splits' sums itself -- same bits
+        assert lib().bm_act_bn_bwd_fused_fallbacks() == fallbacks0, "a workgroup gave up on its partners on an idle chip"
         limit = lib().bm_act_bn_bwd_set_poll_limit(0)
         try:
             alone = run(mode)
         finally:
             lib().bm_act_bn_bwd_set_poll_limit(limit)
+        if lib().bm_act_bn_bwd_fused_covers(B, C, T) and B >= 8:          # (B < 8: one split per channel, no partner)
+            assert lib().bm_act_bn_bwd_fused_fallbacks() > fallbacks0      # the forced fallback is counted
         for a, b in zip(one, alone):
             assert a is None or torch.equal(a, b), f"mode {mode}: the fallback path rounds differently"
         if B * C * T >= 1 << 24:
@@ -213,7 +221,8 @@ def test_one_pass_batchnorm_backward_against_the_two_pass_kernels(H, B, C, T):
         assert float(one[4].max()) == float(one[0].abs().max())      # the published maximum is that of what was written
         if one[5] is not None:
             assert torch.equal(one[5].cpu(), one[0].abs().amax((0, 2)).cpu())
-        assert float(one[3].abs().max()) < 1e-2 * max(1.0, float(one[0].abs().max()))     # sum(dy) of a BN input is ~0
+        if train:
+            assert float(one[3].abs().max()) < 1e-2 * max(1.0, float(one[0].abs().max()))     # sum(dy) of a BN input is ~0
     assert len(results) > 1
     for name, got in results:
         assert rel_l2(got[0], ref) < GRAD_TOL, name

@@ -164,6 +164,74 @@ def test_against_reference_golden(name):
         assert rel_l2(probs, g.t("out/probabilities")) < 1e-5
 
 
+def test_wide_kernels_against_reference_golden():
+    """The headline wide f16x2 kernels held to the LIVE reference directly (not through the oracle): two training steps
+    of the smallest model they cover (hidden 256, depth 4, 64 sensors, T = 192, batch 8; fixture
+    tests/golden/wide_kernels_train.npz, parameters and inputs rebuilt from the seed and checked against the fixture's
+    digests).  The launch labels of step 0 assert that the convs and weight gradients DID run in `conv_nn_h2w` /
+    `gemm_nt_h2w`."""
+    import helpers as Hh
+    from test_oracle_golden import _wide_setup
+    from brainmagick_amd import hip_ops as H
+    from brainmagick_amd.losses import ClipLoss
+    from brainmagick_amd.optim import FlatAdam
+    g, sb, candidates, ban_center, model = _wide_setup()
+    d = Hh.WIDE_DIMS
+    model = model.cuda()
+    model.merger.ban_center_override = ban_center
+    loss_mod = ClipLoss().cuda()
+    batch = _Batch(sb.meg.cuda(), sb.subject_index.cuda(), sb._recordings)
+    cand = candidates.cuda()
+    mask = torch.ones(d["B"], 1, d["T"], dtype=torch.bool, device="cuda")
+    model.train()
+    loss_mod.train()
+    optim = FlatAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.999))
+    gscale = max(float(g.raw[k]) for k in g.raw if k.startswith("grad_norm/"))
+    ref_losses = g.raw["out/losses"]
+    for step in range(2):
+        timer = H.KernelTimer() if step == 0 else None
+        H.set_kernel_timer(timer)
+        try:
+            est = model({"meg": batch.meg.clone()}, batch)
+            loss = loss_mod(est, cand, mask)
+            optim.zero_grad()
+            loss.backward()
+        finally:
+            H.set_kernel_timer(None)
+        if step == 0:
+            labels = [r[0] for r in timer.records]
+            big = [r[0] for r in timer.records if r[1] >= 1e9]
+            n_conv = sum(lb.startswith("conv_nn_h2w_kernel") for lb in labels)
+            n_wg = sum(lb.startswith("gemm_nt_h2w_kernel") for lb in labels)
+            # forward + data-gradient convs of the stack (4 + 2 GLU) and the front end / head; their weight gradients
+            assert n_conv >= 2 * 6 and n_wg >= 6, sorted(set(labels))
+            assert big and all(lb.startswith(("conv_nn_h2w_kernel", "gemm_nt_h2w_kernel")) for lb in big), sorted(set(big))
+            assert rel_l2(est, g.t("out/estimate")) < FWD_TOL
+            for k, p in model.named_parameters():
+                ref_norm = float(g.raw[f"grad_norm/{k}"])
+                if float(g.raw[f"grad_max/{k}"]) <= 1e-5 * gscale:
+                    continue                      # round-off noise in the reference itself (conv bias before BatchNorm)
+                gr = p.grad.detach().flatten().cpu()
+                assert abs(float(gr.double().norm()) - ref_norm) < GRAD_TOL * ref_norm, k
+                idx = Hh.sample_indices(gr.numel())
+                assert (gr[idx].double() - g.t(f"grad_sample/{k}").double()).norm() < 5 * GRAD_TOL * ref_norm, \
+                    (k, float((gr[idx].double() - g.t(f"grad_sample/{k}").double()).norm()), ref_norm)
+        assert abs(float(loss) - ref_losses[step]) < LOSS_TOL, (step, float(loss), ref_losses[step])
+        optim.step()
+    # the sampled parameters after two Adam steps: an element may flip the sign of a noise-level first update
+    # (adam_params_close), everything else agrees tightly
+    lr, bad, total = 3e-4, 0, 0
+    for k, p in model.named_parameters():
+        if float(g.raw[f"grad_max/{k}"]) <= 1e-5 * gscale:
+            continue
+        idx = Hh.sample_indices(p.numel())
+        dlt = (p.detach().flatten().cpu()[idx].double() - g.t(f"sd1_sample/{k}").double()).abs()
+        assert float(dlt.max()) <= 2.1 * lr * 2, k
+        bad += int((dlt > 1e-6).sum())
+        total += len(idx)
+    assert bad <= 0.02 * total, (bad, total)
+
+
 @pytest.mark.parametrize("tag,kw", [("plain", {}), ("pool", dict(pool=True)),
                                     ("center", dict(center=True)), ("trim", None)])
 def test_clip_loss_options_against_golden(tag, kw):
@@ -268,18 +336,24 @@ def test_full_size_step_against_oracle(cfg_name, B):
           f"worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")
 
 
-def test_full_size_horizon_20_steps_against_oracle(steps: int = 20):
-    """The 9 M-parameter paper model at cfg2's FULL size (batch 256, T = 360) for 20 consecutive Adam steps on a
-    stream of 4 distinct batches, side by side with the CPU oracle from the same initial state: the loss of EVERY step
-    within LOSS_TOL (1e-4 absolute), i.e. drift that only shows at depth 10 with BatchNorm over 92 160 samples would
-    show here.  After the last step: BatchNorm running statistics and the parameters (Adam's +-lr noise moves on
-    round-off-level gradients excepted, see adam_params_close).  ~6 s of host time per oracle step on 32 threads."""
+@pytest.mark.parametrize("cfg_name,steps", [("cfg2", 20), ("cfg3", 10), ("cfg5", 10)])
+def test_full_size_horizon_20_steps_against_oracle(cfg_name, steps):
+    """The paper model at FULL size (batch 256, T = 360) for 20 (cfg2: 9 M parameters, mel features) / 10 (cfg3: the
+    640 -> 1024 head and the K = 368 640 score contraction; cfg5: 273 sensors, two layouts, 115 subjects = 230 (layout,
+    subject) groups, 16 M parameters) consecutive Adam steps on a stream of 4 distinct batches, side by side with the CPU
+    oracle from the same initial state: the loss of EVERY step within LOSS_TOL (1e-4 absolute), i.e. drift that only
+    shows at depth 10 with BatchNorm over 92 160 samples would show here.  After the last step: BatchNorm running
+    statistics and the parameters (Adam's +-lr noise moves on round-off-level gradients excepted, see
+    adam_params_close).  ~6 s of host time per oracle step on 32 threads."""
     from brainmagick_amd.solver import Solver
-    c = synthetic.CONFIGS["cfg2"]
+    c = synthetic.CONFIGS[cfg_name]
     # one study: the recordings (and their sensor layouts) are shared by the batches, like in a real training stream
     # (the layouts of a recording are cached by its identity, bm/models/common.py:196-222 does the same)
-    pool = synthetic.make_layouts(4, [c["C"]], torch.Generator().manual_seed(7))
-    batches = [synthetic.make_config_batch("cfg2", seed=2036 + i, batch=256, recordings=pool) for i in range(4)]
+    if cfg_name == "cfg5":
+        pool = synthetic.make_layouts(2, [c["C"], 128], torch.Generator().manual_seed(7))
+    else:
+        pool = synthetic.make_layouts(4, [c["C"]], torch.Generator().manual_seed(7))
+    batches = [synthetic.make_config_batch(cfg_name, seed=2036 + i, batch=256, recordings=pool) for i in range(4)]
     model = _paper_model(c["C"], c["F"], c["S"], seed=2036)
     oracle = O.OracleModel(copy.deepcopy(model.state_dict()), O.CLIP_CONV_CFG, 320, c["F"])
     ban = torch.tensor([0.4, 0.6])
@@ -300,7 +374,7 @@ def test_full_size_horizon_20_steps_against_oracle(steps: int = 20):
             noise |= {k for k, v in grads_ref.items() if is_noise_grad(v, gscale)}
     finally:
         torch.set_num_threads(prev)
-    print(f"full-size horizon: {steps} steps, largest loss gap {max(gaps):.2e} (last loss {float(loss):.6f})")
+    print(f"full-size horizon {cfg_name}: {steps} steps, largest loss gap {max(gaps):.2e} (last loss {float(loss):.6f})")
     # the state after 20 steps.  The per-step losses above are the tight statement (step k + 1's loss sees step k's
     # update); element-wise, 20 Adam steps amplify every round-off-level gradient component into +-lr moves of either
     # sign (adam_params_close), so the parameters are held to: at most 1 % of a tensor's elements further apart than
@@ -323,7 +397,7 @@ def test_full_size_horizon_20_steps_against_oracle(steps: int = 20):
             assert float(d.max()) <= 2.1 * lr * steps, (k, float(d.max()))
         else:
             assert rel_l2(v, ref) < 1e-3, (k, rel_l2(v, ref))
-    print(f"full-size horizon: worst parameter rel-L2 after {steps} steps {worst[0]:.2e} ({worst[1]})")
+    print(f"full-size horizon {cfg_name}: worst parameter rel-L2 after {steps} steps {worst[0]:.2e} ({worst[1]})")
 
 
 def test_offset_meg_ms_slicing_like_the_reference():

@@ -45,6 +45,50 @@ def test_oracle_matches_reference(name):
         assert rel_l2(probs, g.t("out/probabilities")) < 1e-5
 
 
+def _wide_setup():
+    """Inputs and initial state of the wide-kernel fixture, rebuilt from the seed; the fixture's digests prove it."""
+    import helpers as Hh
+    from brainmagick_amd.models import SimpleConv
+    g = Golden("wide_kernels_train")
+    d = Hh.WIDE_DIMS
+    sb, candidates, ban_center, gen = Hh.wide_inputs()
+    torch.manual_seed(d["seed"])
+    model = SimpleConv(in_channels={"meg": d["C"]}, out_channels=d["F"], hidden={"meg": d["hidden"]},
+                       n_subjects=d["S"], **Hh.WIDE_CFG)
+    Hh.randomize_batchnorm(model, gen)
+    for k, v in model.state_dict().items():
+        assert (Hh.tensor_digest(v) == g.raw[f"sd0_digest/{k}"]).all(), f"initial state differs from the fixture's: {k}"
+    assert (Hh.tensor_digest(sb.meg) == g.raw["in_digest/meg"]).all()
+    assert (Hh.tensor_digest(candidates) == g.raw["in_digest/candidates"]).all()
+    assert (Hh.tensor_digest(sb.positions()) == g.raw["in_digest/positions"]).all()
+    assert torch.equal(ban_center, g.t("in/ban_center"))
+    return g, sb, candidates, ban_center, model
+
+
+def test_oracle_matches_reference_at_the_wide_kernel_shape():
+    """The oracle against the live reference's two training steps of the smallest model the wide f16x2 kernels cover
+    (hidden 256, depth 4, 64 sensors, T = 192; tests/golden/make_golden.py: wide_kernels_fixture)."""
+    import helpers as Hh
+    g, sb, candidates, ban_center, model = _wide_setup()
+    d = Hh.WIDE_DIMS
+    oracle = O.OracleModel({k: v.clone() for k, v in model.state_dict().items()}, Hh.WIDE_CFG, d["hidden"], d["F"])
+    losses = []
+    for step in range(2):
+        loss, est, gr = oracle.train_step(sb.meg, sb.positions(), sb.subject_index, candidates, ban_center)
+        losses.append(float(loss))
+        if step == 0:
+            assert rel_l2(est, g.t("out/estimate")) < FWD_TOL
+            gscale = max(float(g.raw[k]) for k in g.raw if k.startswith("grad_norm/"))
+            for k, v in gr.items():
+                ref_norm = float(g.raw[f"grad_norm/{k}"])
+                if float(g.raw[f"grad_max/{k}"]) <= 1e-5 * gscale:
+                    continue                      # round-off noise in the reference itself (conv bias before BatchNorm)
+                assert abs(float(v.double().norm()) - ref_norm) < GRAD_TOL * ref_norm, k
+                idx = Hh.sample_indices(v.numel())
+                assert (v.flatten()[idx].double() - g.t(f"grad_sample/{k}").double()).norm() < 5 * GRAD_TOL * ref_norm, k
+    assert max(abs(a - b) for a, b in zip(losses, g.raw["out/losses"])) < 1e-5
+
+
 def test_oracle_fp64_close_to_fp32_reference():
     g = Golden("clip_conv_eval")
     model = O.OracleModel(g.group("sd0"), g.meta["cfg"], g.meta["hidden"], g.meta["F"],
