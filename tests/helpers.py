@@ -81,17 +81,17 @@ def randomize_batchnorm(model, gen):
 
 
 def tensor_digest(t: torch.Tensor):
-    """(sum, sum of squares, xor of the bit patterns) -- equal digests of two fp32 tensors built by the same code from
-    the same seed mean identical tensors for every practical purpose."""
+    """(wrapping int64 sum, xor, element count) of the fp32 bit patterns: exact integer arithmetic, so the digest does
+    not depend on the host's summation order (a floating-point sum differs between the build container and the GPU
+    box).  Equal digests of two tensors built by the same code from the same seed mean identical tensors for every
+    practical purpose."""
     t = t.detach().cpu().contiguous()
-    if t.is_floating_point():
-        bits = t.float().view(torch.int32).flatten()
-        x = 0
-        for chunk in bits.split(1 << 20):
-            x ^= int(np.bitwise_xor.reduce(chunk.numpy().view(np.uint32))) if chunk.numel() else 0
-        d = t.double()
-        return np.array([float(d.sum()), float((d * d).sum()), float(x)], dtype=np.float64)
-    return np.array([float(t.double().sum()), 0.0, 0.0], dtype=np.float64)
+    if not t.is_floating_point():
+        t = t.float()
+    bits = t.float().view(torch.int32).flatten().numpy()
+    total = int(bits.astype(np.int64).sum()) if bits.size else 0
+    x = int(np.bitwise_xor.reduce(bits.view(np.uint32))) if bits.size else 0
+    return np.array([total, x, bits.size], dtype=np.int64)
 
 
 def sample_indices(numel: int, n: int = 64, seed: int = 0):
