@@ -124,6 +124,72 @@ __device__ __forceinline__ float h2_simple_tile(const H2Simple<MW>& e, f32x16 (&
     return amx;
 }
 
+// Residual tiles (the data-gradient convs of the residual layers: y = conv + bias + res).  Fetched block by block in
+// front of each block's stores -- 16 loads, wait, 16 stores -- a load's wait also waits for the OLDER stores (one in-order
+// counter), so the tile paid fifteen load + store round trips to HBM: 61-67 K cycles per tile against 28 K without a
+// residual (cycle trace, profiles/r6_trace_conv.txt).  Two phases instead: (1) the residual values are added INTO the
+// finished accumulators, loads only, three blocks (48 dword loads per lane) in flight; (2) the stores.  The order of
+// the additions is the old one, (acc x scale + bias) + res.  (`y` may be the residual tensor itself: every element is
+// read in phase 1 and written in phase 2 by the same thread.)
+struct H2Plain {
+    float* yb;
+    const float* rb;
+    int rowu, li, T;
+    int row0, M;
+};
+
+template <int MW, bool FULL>
+__device__ __forceinline__ void h2_residual_add(const H2Plain& e, f32x16 (&acc)[MW][3], int col0, int T) {
+    constexpr int NBLK = MW * 3, D = 3;
+    float rv[D][16];
+    const bool cok[3] = {col0 < T, col0 + 32 < T, col0 + 64 < T};
+    h2_static_for<NBLK + D>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i >= D) {                                   // block i - D has landed
+            constexpr int b = i - D, nt = b / MW, mt = b % MW;
+            if (cok[nt]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rv[b % D][r];
+            }
+        }
+        if constexpr (i < NBLK) {                                 // request block i
+            constexpr int nt = i / MW, mt = i % MW;
+            if (cok[nt]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = mt * 32 + (r & 3) + 8 * (r >> 2);
+                    rv[i % D][r] = (FULL || e.row0 + dr < e.M) ? e.rb[(long)(e.rowu + dr) * e.T + e.li + nt * 32] : 0.f;
+                }
+            }
+        }
+    });
+}
+// the stores of finished accumulators (no bias, no residual left to add)
+template <int MW, int NT, int MT, bool FULL>
+__device__ __forceinline__ float h2_plain_col(const H2Plain& e, f32x16 (&acc)[MW][3], float amx) {
+    if constexpr (MT < MW) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = MT * 32 + (r & 3) + 8 * (r >> 2);
+            const float v = acc[MT][NT][r];
+            if (FULL || e.row0 + dr < e.M) {
+                amx = fmaxf(amx, fabsf(v));
+                e.yb[(long)(e.rowu + dr) * e.T + e.li + NT * 32] = v;
+            }
+        }
+        return h2_plain_col<MW, NT, MT + 1, FULL>(e, acc, amx);
+    }
+    return amx;
+}
+template <int MW, bool FULL>
+__device__ __forceinline__ float h2_plain_tile(const H2Plain& e, f32x16 (&acc)[MW][3], int col0, int T) {
+    float amx = 0.f;
+    if (col0 < T) amx = h2_plain_col<MW, 0, 0, FULL>(e, acc, amx);
+    if (col0 + 32 < T) amx = h2_plain_col<MW, 1, 0, FULL>(e, acc, amx);
+    if (col0 + 64 < T) amx = h2_plain_col<MW, 2, 0, FULL>(e, acc, amx);
+    return amx;
+}
+
 template <int MW, int I>
 __device__ __forceinline__ float h2_general_blocks(const ConvNNArgs& a, f32x16 (&acc)[MW][3], const float* ep, int b,
                                                    int m0, int rl_base, int col_base, float amx) {
@@ -201,13 +267,20 @@ __device__ __forceinline__ void h2_tile_stats(const ConvNNArgs& a, f32x16 (&acc)
 // expansion per accumulator block keeps the accumulators in registers.  `smem` is the workgroup's LDS, free by now
 // (the caller's last barrier): ep[0 .. 3 HBM) = staged row parameters, ep[3 HBM .. 4 HBM) = per-row accumulator
 // factor = inverse weight-row scale x inverse x scale.
-template <int MW>
+template <int MW, bool RESK = false>
 __device__ __forceinline__ void h2_tile_epilogue(const ConvH2Args& args, f32x16 (&acc)[MW][3], float* smem, int b, int g,
                                                  int m0, int n0, int ntile, float sx_inv, int tid, int lane, int wm,
-                                                 int wn, int nl, int h) {
+                                                 int wn, int nl, int h, unsigned* trace_out = nullptr) {
     const ConvNNArgs& a = args.c;
     constexpr int NW = 3;
     constexpr int HBM = 64 * MW;
+#ifdef HG_TRACE
+    unsigned te[6];
+#define H2_TE(I_) { __builtin_amdgcn_sched_barrier(0); te[I_] = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define H2_TE(I_)
+#endif
+    H2_TE(0)
     float* ep = smem;                // the operand buffers are free after the last barrier of the main loop
     conv_ep_stage_params(a, ep, HBM, m0, tid, 256, b);
     {
@@ -215,6 +288,44 @@ __device__ __forceinline__ void h2_tile_epilogue(const ConvH2Args& args, f32x16 
         for (int i = tid; i < HBM; i += 256) ep[3 * HBM + i] = ws[i] * sx_inv;
     }
     __syncthreads();
+    H2_TE(1)
+    if constexpr (RESK) {
+        // The residual kernel: the host launches it only for y_out = conv + bias + res with nothing else in the epilogue,
+        // so this is ALL of it, straight-line: finish the accumulators ((acc x scale) + bias: the fma rounds like the two
+        // steps, acc x scale is exact), add the residual values (loads only, three blocks in flight), store.  The same
+        // updates behind a run-time `if (res)` made hipcc keep two copies of the accumulators (1.3 KB of scratch per
+        // lane, the conv 50 % slower).
+        const float* fl = ep + 3 * HBM + wm * (MW * 32) + 4 * h;
+        const float* bl = ep + wm * (MW * 32) + 4 * h;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = fl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+                const float bb = bl[mt * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                for (int nt = 0; nt < NW; ++nt) acc[mt][nt][r] = fmaf(acc[mt][nt][r], f, bb);
+            }
+        H2Plain e;
+        e.yb = a.y_out + (long)b * a.y_bstride;
+        e.rb = a.res + (long)b * a.res_bstride;
+        e.rowu = m0 + wm * (MW * 32);                       // wave-uniform first row
+        e.li = 4 * h * a.T + n0 + wn * (NW * 32) + nl;      // per-lane element offset inside a row block
+        e.T = a.T;
+        e.row0 = e.rowu + 4 * h;
+        e.M = a.M;
+        const int col0 = n0 + wn * (NW * 32) + nl;
+        float amx;
+        if (m0 + HBM <= a.M) {
+            h2_residual_add<MW, true>(e, acc, col0, a.T);
+            amx = h2_plain_tile<MW, true>(e, acc, col0, a.T);
+        } else {
+            h2_residual_add<MW, false>(e, acc, col0, a.T);
+            amx = h2_plain_tile<MW, false>(e, acc, col0, a.T);
+        }
+        bm_publish_amax(amx, args.y_amax, smem + 4 * HBM);
+        return;
+    }
     {
         const float* fl = ep + 3 * HBM + wm * (MW * 32) + 4 * h;
 #pragma unroll
@@ -226,6 +337,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const ConvH2Args& args, f32x16 
                 for (int nt = 0; nt < NW; ++nt) acc[mt][nt][r] *= f;
             }
     }
+    H2_TE(2)
     // Common case (every wide launch of the training step): one output tensor, no affine / activation.  Row
     // addresses are wave-uniform bases + one per-lane offset + an immediate per column block, the row biases are
     // read once: ~3 VALU issue slots per stored element instead of ~10.  Tiles that straddle M (270-channel
@@ -235,6 +347,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const ConvH2Args& args, f32x16 
                           a.stats + (long)((b * a.ntiles_n + ntile) * 2 + wn) * 2, (long)a.B * a.ntiles_n * 4,
                           m0 + wm * (MW * 32) + 4 * h, n0 + wn * (NW * 32) + nl, lane);
     const bool simple = ((a.y_pre != nullptr) != (a.y_out != nullptr)) && !a.ep_scale && a.act == BM_ACT_NONE;
+    H2_TE(3)
     if (simple) {
         H2Simple<MW> e;
         e.yb = (a.y_pre ? a.y_pre : a.y_out) + (long)b * a.y_bstride;
@@ -252,7 +365,15 @@ __device__ __forceinline__ void h2_tile_epilogue(const ConvH2Args& args, f32x16 
         const int col0 = n0 + wn * (NW * 32) + nl;
         const float amx = m0 + HBM <= a.M ? h2_simple_tile<MW, true>(e, acc, col0, a.T)
                                           : h2_simple_tile<MW, false>(e, acc, col0, a.T);
+        H2_TE(4)
         if (a.y_out) bm_publish_amax(amx, args.y_amax, smem + 4 * HBM);
+        H2_TE(5)
+#ifdef HG_TRACE
+        if (trace_out && blockIdx.x < 64 && lane == 0) {       // [0][1..3], [1][1..2]: staging, scales, BatchNorm sums, stores, amax
+            unsigned* o = trace_out + ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 3) * 8;
+            o[1] = te[1] - te[0]; o[2] = te[2] - te[1]; o[3] = te[3] - te[2]; o[8 + 1] = te[4] - te[3]; o[8 + 2] = te[5] - te[4];
+        }
+#endif
     } else {
         const float amx = h2_general_blocks<MW, 0>(a, acc, ep, b, m0, wm * (MW * 32) + 4 * h,
                                                    n0 + wn * (NW * 32) + nl, 0.f);

@@ -281,7 +281,11 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2d_kernel(ConvH2Args args) {
 #undef TERM
 #undef CH_BARRIER
 
+#ifdef HG_TRACE
+    h2_tile_epilogue<MW>(args, acc, smem, b, g, m0, n0, ntile, sx_inv, tid, lane, wm, wn, nl, h, ch_trace_buf);
+#else
     h2_tile_epilogue<MW>(args, acc, smem, b, g, m0, n0, ntile, sx_inv, tid, lane, wm, wn, nl, h);
+#endif
 #ifdef HG_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile's stores have left the CU
     if (blockIdx.x < 64 && lane == 0) {

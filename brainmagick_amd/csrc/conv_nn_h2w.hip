@@ -109,7 +109,8 @@ constexpr H2RItem h2r_item(int i) {
     return H2RItem{H2R_BREAD, i};
 }
 
-template <int KS, int MW>
+// RESK: the epilogue of y_out = conv + bias + residual alone (conv_h2_common.h: h2_residual_add), a kernel of its own
+template <int KS, int MW, bool RESK = false>
 __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
     const ConvNNArgs& a = args.c;
 #ifdef HG_TRACE
@@ -289,7 +290,11 @@ __global__ __launch_bounds__(256, 1) void conv_nn_h2w_kernel(ConvH2Args args) {
 #undef H2R_SOFF
 #undef H2R_LOAD_X
 
-    h2_tile_epilogue<MW>(args, acc, smem, b, g, m0, n0, ntile, sx_inv, tid, lane, wm, wn, nl, h);
+#ifdef HG_TRACE
+    h2_tile_epilogue<MW, RESK>(args, acc, smem, b, g, m0, n0, ntile, sx_inv, tid, lane, wm, wn, nl, h, ch_trace_buf);
+#else
+    h2_tile_epilogue<MW, RESK>(args, acc, smem, b, g, m0, n0, ntile, sx_inv, tid, lane, wm, wn, nl, h);
+#endif
 #ifdef HG_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile's stores have left the CU
     if (blockIdx.x < 64 && lane == 0) {
@@ -557,10 +562,17 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
     // BM_CONV_LDSDMA=1: the round-2..5 main loop (weight slabs by LDS-DMA, a barrier per stage; conv_nn_h2d.hip), for A/B runs
     static const bool ldsdma = [] { const char* e = getenv("BM_CONV_LDSDMA"); return e && e[0] == '1'; }();
     if (!ldsdma) lds = (size_t)(2 * HXSLAB) * 16 > lds_ep ? (size_t)(2 * HXSLAB) * 16 : lds_ep;
+    // y_out = conv + bias + residual and nothing else (the data-gradient convs of the residual layers, all 3-tap): the
+    // kernel with the two-phase residual epilogue
+    const ConvNNArgs& c = args.c;
+    const bool resk = KS == 3 && !ldsdma && c.res && c.y_out && !c.y_pre && !c.ep_scale && !c.stats && c.act == BM_ACT_NONE;
     static bool attr_set = false;
     if (!ldsdma && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_h2w_kernel<KS, MW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_h2w_kernel<KS, MW, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && KS == 3)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nn_h2w_kernel<KS, MW, KS == 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return bm_set_error((int)e, "conv_nn_h2w: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -574,8 +586,10 @@ static int launch_conv_nn_h2w(ConvH2Args args, float* y_amax_out, hipStream_t st
     if (!publish) args.y_amax = BmAmaxDst{nullptr};
     if (ldsdma) {
         if (int rc = bm_launch_conv_nn_h2d(args, KS, MW, lds, (unsigned)nblocks, stream)) return rc;
-    } else
-        hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
+    } else if (resk)
+        hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW, KS == 3>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
+    else
+        hipLaunchKernelGGL((conv_nn_h2w_kernel<KS, MW, false>), dim3((unsigned)nblocks), dim3(256), lds, stream, args);
     if (int rc = bm_check_launch("conv_nn_h2w")) return rc;
     if (publish) return bm_amax_done(args.y_amax, (int)nblocks, y_amax_out, stream);
     if (y_amax_out && ws)           // grid larger than the workspace: a plain pass over the output instead
