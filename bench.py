@@ -106,10 +106,15 @@ def pmc_traffic(kernel_label: str):
         return None, None, None
     data = json.loads(files[-1].read_text())
     prefix = kernel_label.rstrip(">").replace(" ", "")
-    for name, rec in data.get("kernels", {}).items():
-        if name.replace(" ", "").replace("void", "", 1).startswith(prefix):
-            avg = rec.get("avg_ns")
-            return rec.get("hbm_bytes_per_launch_corrected"), files[-1].name, (avg * 1e-6 if avg else None)
+    nb = nt = nn = 0.0
+    for name, rec in data.get("kernels", {}).items():       # launch-weighted over the label's instantiations
+        if name.replace(" ", "").replace("void", "", 1).startswith(prefix) and rec.get("hbm_bytes_per_launch_corrected"):
+            n = float(rec.get("launches") or 1)
+            nb += rec["hbm_bytes_per_launch_corrected"] * n
+            nt += (rec.get("avg_ns") or 0.0) * n
+            nn += n
+    if nn:
+        return nb / nn, files[-1].name, (nt / nn * 1e-6 if nt else None)
     return None, files[-1].name, None
 
 
@@ -162,6 +167,7 @@ def traffic_from_counters(fetch, write, kernel_label, child_steps):
     per_launch = launches = None
     total = 0.0
     table = {}
+    dom_bytes, dom_n = 0.0, 0
     for k, (n, f) in fetch.items():
         w = write.get(k)
         if w is None:
@@ -169,8 +175,11 @@ def traffic_from_counters(fetch, write, kernel_label, child_steps):
         b = (2.0 * f / n + w[1] / w[0]) * 1024.0
         total += b * n
         table[k] = {"launches_per_step": n / child_steps, "hbm_bytes_per_launch": b}
-        if k.replace(" ", "").startswith(prefix):
-            per_launch, launches = b, n
+        if k.replace(" ", "").startswith(prefix):       # every instantiation of the label (e.g. <3,5,false> and <3,5,true>)
+            dom_bytes += b * n
+            dom_n += n
+    if dom_n:
+        per_launch, launches = dom_bytes / dom_n, dom_n
     top = dict(sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"])[:12])
     return per_launch, launches, total / child_steps, top
 

@@ -867,6 +867,13 @@ def test_bench_reads_the_counter_passes_like_the_guide_prescribes(tmp_path):
     assert n == 2 and per_launch == (2 * 200.0 + 50.0) * 1024
     assert step_bytes == 2 * per_launch + (2 * 50.0 + 60.0) * 1024
     assert list(top)[0] == "conv_nn_h2w_kernel<3, 5>"
+    # the label covers every instantiation of the kernel (round 6: <3, 5, false> and the residual-epilogue <3, 5, true>):
+    # launch-weighted bytes per launch
+    fetch2 = {"conv_nn_h2w_kernel<3, 5, false>": [3, 300.0], "conv_nn_h2w_kernel<3, 5, true>": [1, 200.0]}
+    write2 = {"conv_nn_h2w_kernel<3, 5, false>": [3, 150.0], "conv_nn_h2w_kernel<3, 5, true>": [1, 80.0]}
+    per_launch, n, step_bytes, _ = bench.traffic_from_counters(fetch2, write2, "conv_nn_h2w_kernel<3,5>", child_steps=1)
+    assert n == 4 and per_launch == pytest.approx(((2 * 300.0 + 150.0) + (2 * 200.0 + 80.0)) * 1024 / 4)
+    assert step_bytes == pytest.approx(per_launch * 4)
 
 
 def test_comm_timer_is_inert_without_a_gpu_and_names_the_phases():
