@@ -3,6 +3,14 @@ arguments, parameter / buffer names (``state_dict`` keys) and error behaviour as
 with every tensor op replaced by libbmhip kernels (``brainmagick_amd.functional``).
 
 Modules only hold parameters and sequence the HIP ops; they raise on CPU tensors (no fallback).
+
+What is the reference's own text here, said plainly: the three small helpers ``ScaledEmbedding``
+(bm/models/common.py:28-42), ``LayerScale`` (:65-76) and ``pad_multiple`` (:22-25) are the reference's code as is
+(a few lines each, off the hot path, torch ops only), and the CONSTRUCTORS of ``ConvSequence``, ``ChannelMerger``,
+``SubjectLayers`` and ``PositionGetter.get_positions / is_invalid`` follow the reference statement by statement, because
+module order, attribute names and the order of the random draws ARE the interoperability contract (``state_dict`` keys,
+same-seed initialisation: tests/golden/make_golden.py asserts bit-identical parameters from the same seed).  Every
+``forward`` is written over the HIP ops.
 """
 from functools import partial
 import math
