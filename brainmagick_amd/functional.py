@@ -411,12 +411,16 @@ class ClipLossFn(torch.autograd.Function):
     row term and the column term (every target candidate classifies the estimates, `bm_clip_ce_cols`)."""
 
     @staticmethod
-    def forward(ctx, estimate, candidate, target_offset: int = 0, col_valid=None, symmetric: bool = False):
+    def forward(ctx, estimate, candidate, target_offset: int = 0, col_valid=None, symmetric: bool = False,
+                normalize: bool = True):
+        """``normalize=False`` (the node-wide column term, losses.ClipLoss): the scores are the plain products
+        est . cand -- no candidate norms in the forward pass, no norm correction in the candidates' gradient."""
         estimate, candidate = _c(estimate), _c(candidate)
         B, Bc = estimate.shape[0], candidate.shape[0]
         K = estimate.numel() // B
         assert candidate.numel() // Bc == K
-        inv = H.clip_inv_norms(candidate)
+        inv = H.clip_inv_norms(candidate) if normalize else torch.ones(Bc, device=candidate.device, dtype=torch.float32)
+        ctx.normalize = normalize
         part = _clip_raw_scores(estimate, candidate, B, Bc, K)
         scores, _, dscaled, loss = H.clip_ce(part, inv, want_grad=True, want_loss=True,
                                              target_offset=target_offset, col_valid=col_valid)
@@ -458,10 +462,11 @@ class ClipLossFn(torch.autograd.Function):
                 wpt = H.pack_weights(dscaled.view(-1)[r0:], 1, rows, B, 1, 0, 1, Bc, 0, alpha=alpha, shape=(K, 1))
                 H.conv_nn(estimate.view(1, B, K), wpt, rows, 1, 1,
                           out=dcand[r0:r0 + rows] if len(blocks) > 1 else dcand)
-            coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
-            H.row_axpy_sub(dcand, cand2, coef)
+            if ctx.normalize:
+                coef = H.clip_cand_coef(dscaled, scores, inv, alpha)
+                H.row_axpy_sub(dcand, cand2, coef)
             dcand = dcand.view(ctx.cand_shape)
-        return dest, dcand, None, None, None
+        return dest, dcand, None, None, None, None
 
 
 def clip_scores(estimate, candidate, want_probs=False):

@@ -81,13 +81,17 @@ class ClipLoss(torch.nn.Module):
         estimates, candidates = self._prepare(estimates, candidates)
         return BF.clip_scores(estimates.detach(), candidates.detach(), want_probs=True)
 
-    def forward(self, estimate, candidate, mask=None, target_offset: int = 0, candidate_valid=None):
+    def forward(self, estimate, candidate, mask=None, target_offset: int = 0, candidate_valid=None, estimate_all=None):
         """The first B candidates are the targets of the B estimates, the remaining B'-B are only
         negatives (losses.py:104-114).  ``target_offset`` (extension, default 0 = reference
         behaviour) shifts the targets to candidates [offset, offset+B): a data-parallel rank uses
         it to point at its own block of the whole-node gathered candidates.  ``candidate_valid``
         (extension, [B'] fp32, default None = all): candidates marked 0 are padding (ranks that rejected
-        different numbers of segments bring equal-sized, partly empty blocks) and never count as negatives."""
+        different numbers of segments bring equal-sized, partly empty blocks) and never count as negatives.
+        ``estimate_all`` (extension, with ``symmetric``): the estimates of EVERY rank, gathered with an autograd-aware
+        all-gather, this rank's block at rows [offset, offset+B) -- the column term then lets each of this rank's target
+        candidates classify the whole node's estimates (north_star: "all-gather of brain/audio embeddings ... so the
+        negatives pool is whole-node" for the column softmax too); without it the column term sees the local estimates."""
         if self.defer_mask_check and mask.is_cuda and mask.dtype == torch.bool:
             # Solver: the reference's assert costs a host sync in the middle of the step; the verdict is OR-ed into
             # the device-side flag word and raised at the next step's single synchronisation point
@@ -98,5 +102,31 @@ class ClipLoss(torch.nn.Module):
             assert mask.all(), "mask is not supported for now"
         assert estimate.size(0) + target_offset <= candidate.size(0), \
             "need at least as many targets as estimates"
+        if self.symmetric and estimate_all is not None:
+            return self._symmetric_over_the_node(estimate, candidate, target_offset, candidate_valid, estimate_all)
         estimate, candidate = self._prepare(estimate, candidate)
         return BF.ClipLossFn.apply(estimate, candidate, target_offset, candidate_valid, self.symmetric)[0]
+
+    def _symmetric_over_the_node(self, estimate, candidate, target_offset, candidate_valid, estimate_all):
+        """(row term + column term) / 2 with whole-node negatives on BOTH sides.  Row term: this rank's estimates
+        against all candidates (as without ``symmetric``).  Column term: this rank's target candidates j against ALL
+        estimates i, CE over i of s[i, j] = est_i . cand_j / ||cand_j|| with the target at row offset + j -- computed as
+        the row term of the transposed problem: "estimates" = the target candidates scaled by their inverse norms,
+        "candidates" = the gathered estimates, unnormalised; its gradient flows into ``estimate_all`` and through the
+        all-gather's adjoint (a reduce-scatter) back to every rank's encoder."""
+        if candidate_valid is not None:
+            raise NotImplementedError("the node-wide column term needs the same number of segments on every rank "
+                                      "(candidate_valid marks padding blocks of ranks that rejected segments)")
+        if candidate.requires_grad:
+            raise NotImplementedError("the node-wide column term is built for constant candidates")
+        from . import hip_ops as H
+        B = estimate.size(0)
+        assert estimate_all.size(0) >= target_offset + B
+        est, cand = self._prepare(estimate, candidate)
+        rows = BF.ClipLossFn.apply(est, cand, target_offset, None, False)[0]
+        est_all, _ = self._prepare(estimate_all, candidate)
+        targets = cand[target_offset:target_offset + B]
+        inv = H.clip_inv_norms(targets.contiguous())
+        scaled = (targets * inv.view(-1, 1, 1)).contiguous()
+        cols = BF.ClipLossFn.apply(scaled, est_all, target_offset, None, False, False)[0]
+        return 0.5 * (rows + cols)

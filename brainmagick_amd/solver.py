@@ -283,6 +283,13 @@ class Solver:
             return self._gather.wait()
         return distrib.gather_learnable_candidates(output) + (None,)
 
+    def _gathered_estimates(self, estimate):
+        """``ClipLoss(symmetric=True)`` with whole-node negatives: the column term needs every rank's estimates (the
+        all-gather of brain embeddings north_star names; its adjoint reduce-scatters their gradients back)."""
+        if self.negatives == "node" and getattr(self.loss, "symmetric", False):
+            return {"estimate_all": distrib.gather_learnable_candidates(estimate)[0]}
+        return {}
+
     def _complete_with_pool(self, output, training: bool):
         """bm/solver.py:358-371: with ``optim.negatives`` set, fewer candidates than that are completed with a random
         draw from the pool of earlier candidates, and the pool takes the completed set in front."""
@@ -327,7 +334,8 @@ class Solver:
             self._last_batch = batch
         output, target_offset, valid = self._candidates(output)
         output = self._complete_with_pool(output, training=True)
-        loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid)
+        loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid,
+                         **self._gathered_estimates(estimate))
         if next_batch is not None:
             self.prefetch(next_batch)       # the next step's candidate all-gather runs next to this backward
         # bm/solver.py:375-380: `training_penalty` of every module that has one (ChannelMerger with merger_penalty:
@@ -423,7 +431,8 @@ class Solver:
         estimate, output, features_mask, _ = self._process_batch(batch, training=False)
         output, target_offset, valid = self._candidates(output)
         output = self._complete_with_pool(output, training=False)
-        loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid)
+        loss = self.loss(estimate, output, features_mask, target_offset=target_offset, candidate_valid=valid,
+                         **self._gathered_estimates(estimate))
         # the mask assert of THIS call is deferred to the flag word: an evaluation loop has no next train_step that
         # would read it (one small read-back per evaluation batch; the reference's assert synchronises as well)
         self.check_pending_flags()

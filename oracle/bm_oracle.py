@@ -338,6 +338,18 @@ def clip_loss_symmetric(estimate: torch.Tensor, candidate: torch.Tensor, target_
     return 0.5 * (rows + cols)
 
 
+def clip_loss_symmetric_node(estimate_all: torch.Tensor, candidate_all: torch.Tensor, rank: int, B: int, **kw) -> torch.Tensor:
+    """NOT in the reference: the symmetric objective of ``clip_loss_symmetric`` with whole-node negatives on both sides,
+    as rank ``rank`` of a data-parallel run sees it -- its B estimates (rows [rank B, (rank + 1) B) of the gathered
+    estimates) against every candidate, and its B target candidates against every estimate.  Checker of
+    ``ClipLoss(symmetric=True)`` under ``negatives="node"`` (brainmagick_amd/losses.py)."""
+    scores = clip_scores(estimate_all, candidate_all, **kw)             # [N B, N B], candidate norms applied
+    own = torch.arange(B) + rank * B
+    rows = F.cross_entropy(scores[own], own)
+    cols = F.cross_entropy(scores[:, own].t(), own)
+    return 0.5 * (rows + cols)
+
+
 def topk_accuracy(probs: torch.Tensor, labels: torch.Tensor, row_labels: torch.Tensor,
                   topk: int = 10) -> float:
     """scripts/run_eval_probs.py:237-264 _get_accuracy_from_probs, segment-level: a row is a hit

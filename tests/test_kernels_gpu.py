@@ -550,6 +550,33 @@ def test_symmetric_clip_loss(B, Bc, off):
     assert abs(float(rows) - float(ref_rows)) < 1e-5
 
 
+@pytest.mark.parametrize("world,rank,B", [(1, 0, 12), (3, 1, 8), (2, 1, 136)])
+def test_symmetric_clip_loss_over_gathered_estimates(world, rank, B):
+    """``ClipLoss(symmetric=True)`` with ``estimate_all`` (whole-node negatives on both sides: the column term of a
+    rank's target candidates runs over EVERY rank's estimates): loss and the gradient w.r.t. all estimate blocks against
+    the fp64 restatement; at world 1 it equals the local symmetric loss.  (136: the wide score kernel.)"""
+    from brainmagick_amd.losses import ClipLoss
+    g = _gen(world * 100 + rank * 10 + B)
+    Fd, T = 6, 40
+    cand = torch.randn(world * B, Fd, T, generator=g, dtype=torch.float64) * 1.5
+    blocks = [(torch.randn(B, Fd, T, generator=g, dtype=torch.float64) + 0.05 * cand[r * B:(r + 1) * B]).requires_grad_(True)
+              for r in range(world)]
+    ref = O.clip_loss_symmetric_node(torch.cat(blocks), cand, rank, B)
+    (ref * 0.7).backward()
+    dev = [b.detach().float().cuda().requires_grad_(True) for b in blocks]
+    est_all = torch.cat(dev)
+    mask = torch.ones(B, 1, T, dtype=torch.bool, device="cuda")
+    loss = ClipLoss(symmetric=True).cuda()(dev[rank], cand.float().cuda(), mask, target_offset=rank * B,
+                                           estimate_all=est_all)
+    (loss * 0.7).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5, (float(loss), float(ref))
+    for r in range(world):
+        assert rel_l2(dev[r].grad, blocks[r].grad) < GRAD_TOL, (r, rel_l2(dev[r].grad, blocks[r].grad))
+    if world == 1:
+        local = ClipLoss(symmetric=True).cuda()(dev[0].detach(), cand.float().cuda(), mask)
+        assert abs(float(local) - float(loss)) < 1e-5
+
+
 @pytest.mark.parametrize("n_neg", [None, 40])
 def test_word_level_wer_batched(H, n_neg):
     """retrieval.get_wer (one GEMM + row kernels) vs the reference's per-segment loop (bm/wer.py:91-120)."""

@@ -858,6 +858,56 @@ def test_two_replicas_with_learnable_candidates_match_joint_autograd():
         assert rel_l2(res[r]["grad_shard"] / world, full[lo:hi]) < GRAD_TOL, (r, rel_l2(res[r]["grad_shard"] / world, full[lo:hi]))
 
 
+def test_two_replicas_with_the_symmetric_loss_gather_their_estimates():
+    """``ClipLoss(symmetric=True)`` under whole-node negatives at world size 2 (loopback communicator): the estimates of
+    both ranks are gathered with the autograd-aware all-gather, so each rank's target candidates classify the whole
+    node's estimates and the gradient of a rank's column term reaches the OTHER rank's encoder through the
+    reduce-scatter.  Oracle = torch autograd on the CPU over both ranks jointly (`clip_loss_symmetric_node`); compared:
+    per-rank losses and the reduce-scattered gradient shards."""
+    from loopback import run_replicas
+    from brainmagick_amd import distrib
+    from brainmagick_amd.losses import ClipLoss
+    from brainmagick_amd.models import SimpleConv
+    from brainmagick_amd.solver import Solver
+    world, B = 2, 6
+    cfg = dict(O.CLIP_CONV_CFG)
+    cfg.update(merger_pos_dim=128, merger_channels=24, initial_linear=24, depth=4, merger_dropout=0.0)
+    C, T, Fd, S, hidden = 20, 64, 12, 3, 32
+
+    def build():
+        torch.manual_seed(2)
+        return SimpleConv(in_channels={"meg": C}, out_channels=Fd, hidden={"meg": hidden}, n_subjects=S, **cfg)
+
+    sd_m = copy.deepcopy(build().state_dict())
+    recordings = synthetic.make_layouts(1, [C], torch.Generator().manual_seed(4))
+    batches = [synthetic.make_batch(B, C, T, Fd, S, seed=90 + r, recordings=recordings) for r in range(world)]
+
+    def body(r):
+        model = build()
+        solver = Solver(model, loss=ClipLoss(symmetric=True), negatives="node")
+        loss = float(solver.train_step(batches[r]))
+        opt = solver.optimizer
+        lo, hi = distrib.shard_bounds(opt.padded, world, r)
+        return dict(loss=loss, shard=(lo, hi), grad_shard=opt.flat_grad[lo:hi].clone().cpu(),
+                    names=[k for k, _ in model.named_parameters()], offsets=list(opt.offsets))
+
+    res = run_replicas(world, body)
+    om = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd_m.items()}
+    ests = [O.simpleconv_forward(om, cfg, sb.meg, sb.positions(), sb.subject_index, hidden, Fd, training=True)
+            for sb in batches]
+    cand_all = torch.cat([sb.features for sb in batches])
+    losses = [O.clip_loss_symmetric_node(torch.cat(ests), cand_all, r, B) for r in range(world)]
+    (sum(losses) / world).backward()
+    for r in range(world):
+        assert abs(res[r]["loss"] - float(losses[r])) < LOSS_TOL, (r, res[r]["loss"], float(losses[r]))
+    full = torch.zeros(max(res[0]["offsets"]) + 10 ** 6, dtype=torch.float64)
+    for k, off in zip(res[0]["names"], res[0]["offsets"]):
+        full[off:off + om[k].grad.numel()] = om[k].grad.reshape(-1).double()
+    for r in range(world):
+        lo, hi = res[r]["shard"]
+        assert rel_l2(res[r]["grad_shard"] / world, full[lo:hi]) < GRAD_TOL, (r, rel_l2(res[r]["grad_shard"] / world, full[lo:hi]))
+
+
 def test_bench_self_launches_on_two_gpus_when_visible():
     """`python bench.py --gpus 2` outside a torchrun environment re-launches itself under torch.distributed.run, one
     rank per GPU over the C-ABI RCCL communicator, whole-node negatives with the candidate gather prefetched; rank 0

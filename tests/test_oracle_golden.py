@@ -206,3 +206,20 @@ def test_symmetric_restatement_is_the_mean_of_the_two_directions():
     assert float(O.clip_loss_symmetric(est, cand, target_offset=off)) == pytest.approx(float(0.5 * (rows + cols)), abs=1e-12)
     assert float(O.clip_loss(est, cand)) == pytest.approx(
         float(sum(torch.logsumexp(s[b], 0) - s[b, b] for b in range(B)) / B), abs=1e-12)
+
+
+def test_symmetric_node_restatement_against_plain_loops():
+    """`O.clip_loss_symmetric_node` (checker of the symmetric loss with whole-node negatives on both sides) against
+    plain loops: rank r's rows against every candidate, its target candidates' columns against every estimate."""
+    g = torch.Generator().manual_seed(5)
+    world, B, r = 3, 4, 1
+    est = torch.randn(world * B, 3, 5, generator=g, dtype=torch.float64)
+    cand = torch.randn(world * B, 3, 5, generator=g, dtype=torch.float64)
+    s = O.clip_scores(est, cand)
+    own = [r * B + k for k in range(B)]
+    rows = sum(torch.logsumexp(s[i], 0) - s[i, i] for i in own) / B
+    cols = sum(torch.logsumexp(s[:, j], 0) - s[j, j] for j in own) / B
+    assert float(O.clip_loss_symmetric_node(est, cand, r, B)) == pytest.approx(float(0.5 * (rows + cols)), abs=1e-12)
+    # one rank: the local symmetric loss
+    assert float(O.clip_loss_symmetric_node(est[:B], cand[:B], 0, B)) == pytest.approx(
+        float(O.clip_loss_symmetric(est[:B], cand[:B])), abs=1e-12)
