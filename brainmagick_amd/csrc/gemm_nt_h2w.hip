@@ -118,6 +118,17 @@ __device__ __forceinline__ void hg_split_pair(float x0, float x1, float s0, floa
         : "v"(x0), "v"(x1), "v"(s0), "v"(s1));
 }
 
+// the two halves of hg_split_pair as separate statements (2 VALU each): the main loop puts them behind different MFMAs
+__device__ __forceinline__ void hg_split_hi(float x0, float x1, float s0, float s1, unsigned& hi) {
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\t"
+        "v_fma_mixhi_f16 %0, %2, %4, 0" : "=&v"(hi) : "v"(x0), "v"(x1), "v"(s0), "v"(s1));
+}
+__device__ __forceinline__ void hg_split_lo(float x0, float x1, float s0, float s1, unsigned hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %5, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo) : "v"(hi), "v"(x0), "v"(x1), "v"(s0), "v"(s1));
+}
+
 // lgkmcnt(0) + workgroup barrier; names A.hi / B.hi as operands so that the register-only MFMAs that read them
 // stay on their side of the barrier (see conv_nn_h2w.hip)
 template <int MW, int NS>
@@ -375,6 +386,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
         *reinterpret_cast<u32x2*>(dst_ + PLANE * 16) = u32x2{pw[0], pw[1]};                       \
     }
 #define HG_STORE(I_, WB_) { HG_SPLIT0(I_) HG_SPLIT1(I_) HG_WRITE(I_, WB_) }
+    // the same split in four sub-steps of 2 VALU (hi / lo of samples 0-1, hi / lo of samples 2-3)
+#define HG_SPLIT_SUB(I_, Q_)                                                                      \
+    {                                                                                             \
+        if constexpr ((Q_) == 0) hg_split_hi(__uint_as_float(rp[I_][0]), __uint_as_float(rp[I_][1]), HG_S(I_, 0), HG_S(I_, 1), ph[0]); \
+        if constexpr ((Q_) == 1) hg_split_lo(__uint_as_float(rp[I_][0]), __uint_as_float(rp[I_][1]), HG_S(I_, 0), HG_S(I_, 1), ph[0], pw[0]); \
+        if constexpr ((Q_) == 2) hg_split_hi(__uint_as_float(rp[I_][2]), __uint_as_float(rp[I_][3]), HG_S(I_, 2), HG_S(I_, 3), ph[1]); \
+        if constexpr ((Q_) == 3) hg_split_lo(__uint_as_float(rp[I_][2]), __uint_as_float(rp[I_][3]), HG_S(I_, 2), HG_S(I_, 3), ph[1], pw[1]); \
+    }
     unsigned ph[2], pw[2];
     // one operand fragment set, rolling over the k-steps: [plane 0 = hi, 1 = lo]; k-step KK_ of the stage in
     // buffer RB_ (u32x4*): group 2 KK_ + h of the lane's row
@@ -469,16 +488,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
                     if constexpr (w < MW) HG_READ_A1(1, nb, 0, w)
                     else if constexpr (w < MW + NS) HG_READ_B1(0, nb, 0, w - MW)
                 }
-                // piece p: sub-steps behind MFMAs p * 5 TN / NP + 0, 1, 2
+                // piece p in FIVE sub-steps (split hi / lo of samples 0-1, hi / lo of samples 2-3: 2 VALU each; the two
+                // LDS writes + the refill fetch), the 5 NP sub-steps spread evenly over the 5 TN slots of the first five
+                // terms -- whole 4-VALU pairs behind one MFMA overran its 32 cycles (cycle trace: 3 246 cycles for the
+                // 75 MFMAs = 2 400 of these terms)
                 if constexpr (n < 5 * TN) {
-                    constexpr int p = ((n + 1) * NP + 5 * TN - 1) / (5 * TN) - 1;        // last piece starting at <= n
-                    constexpr int n0 = p * 5 * TN / NP;
-                    if constexpr (n == n0) HG_SPLIT0(p)
-                    if constexpr (n == n0 + 1) HG_SPLIT1(p)
-                    if constexpr (n == n0 + 2) {
-                        HG_WRITE(p, wb)
-                        HG_FETCH(p)
-                    }
+                    constexpr int NSUB = 5 * NP, NSL = 5 * TN;
+                    constexpr int q0 = (n * NSUB + NSL - 1) / NSL, q1 = ((n + 1) * NSUB + NSL - 1) / NSL;
+                    hg_static_for<q1 - q0>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = q0 + decltype(qc)::value, p = q / 5, sub = q % 5;
+                        if constexpr (sub < 4) HG_SPLIT_SUB(p, sub)
+                        else {
+                            HG_WRITE(p, wb)
+                            HG_FETCH(p)
+                        }
+                    });
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -507,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #undef HG_SV
 #undef HG_S
 #undef HG_SPLIT0
+#undef HG_SPLIT_SUB
 #undef HG_SPLIT1
 #undef HG_WRITE
 #undef HG_READ_A1
