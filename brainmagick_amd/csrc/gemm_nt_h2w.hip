@@ -441,16 +441,23 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
         // the last stage: split and stored like any other, never read).  Spread over the first five terms, piece
         // by piece: split the piece into buffer (k + 1) & 1, fetch the same piece of chunk k + 2 into its
         // registers.  Barrier before the last term, which covers the first fragment reads of stage k + 1.
+        // per-stage bookkeeping (edge scales of the chunk in the staging set, offsets of the chunk to fetch next): for
+        // stage 0 here, for stage k + 1 behind the MFMAs of stage k's last term (in front of the loop's MFMA stream it
+        // cost ~200 cycles per stage during which the matrix pipe idled: cycle trace, "wait loads")
+#define HG_BOOKKEEPING()                                                                          \
+        {                                                                                         \
+            const bool edge = t0c - halo < 0 || t0c + HG_K + halo > a.T;                          \
+            if (edge || was_edge) HG_SET_SCALES(t0c)                                              \
+            was_edge = edge;                                                                      \
+            HG_CHUNK_OFFSETS()                                                                    \
+            HG_MARK()                                                                             \
+        }
+        HG_BOOKKEEPING()
         for (int k = 0; k < nst; ++k) {
             HG_T(0)
             const u32x4* rb = lds + (k & 1) * BUF;
             const u32x4* nb = lds + ((k + 1) & 1) * BUF;
             char* wb = reinterpret_cast<char*>(lds + ((k + 1) & 1) * BUF);
-            const bool edge = t0c - halo < 0 || t0c + HG_K + halo > a.T;
-            if (edge || was_edge) HG_SET_SCALES(t0c)
-            was_edge = edge;
-            HG_CHUNK_OFFSETS()
-            HG_MARK()
             HG_T(1)
             // One slot per MFMA, in source order (scheduling fence after each): the MFMA, then at most one
             // fragment read and one sub-step of a piece -- a lone wavefront per SIMD issues one instruction every
@@ -504,9 +511,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
                         }
                     });
                 }
+                // the next stage's bookkeeping: behind the early fragment reads of the last term (every split and
+                // fetch of this stage is issued by then)
+                if constexpr (n == 5 * TN + MW + NS) HG_ADVANCE()
+                if constexpr (n == 5 * TN + MW + NS + 1) HG_BOOKKEEPING()
                 __builtin_amdgcn_sched_barrier(0);
             });
-            HG_ADVANCE()
 #ifdef HG_TRACE
             HG_T(6)
             tacc[0] += tr[1] - tr[0]; tacc[1] += tr[4] - tr[1]; tacc[4] += tr[5] - tr[4]; tacc[5] += tr[6] - tr[5];
@@ -532,6 +542,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_h2w_kernel(GemmNTArgsH a) {
 #undef HG_S
 #undef HG_SPLIT0
 #undef HG_SPLIT_SUB
+#undef HG_BOOKKEEPING
 #undef HG_SPLIT1
 #undef HG_WRITE
 #undef HG_READ_A1
