@@ -20,7 +20,7 @@ int bm_check_launch(const char* what) {
 }
 
 extern "C" const char* bm_last_error(void) { return bm_err_buf; }
-extern "C" int bm_version(void) { return 105; }   // 0.1.5: round 4 (bm_clip_ce_masked, bm_clip_ce_cols, bm_gemm_nt_h2_grouped; bf16 / x3w / atomic-amax entry points removed)
+extern "C" int bm_version(void) { return 106; }   // 0.1.6: round 6 (bm_act_bn_bwd_fused_fallbacks; the wide conv reads its packed weights straight into fragment registers -- same entry points, same packed layout)
 
 // Number of HIP devices visible; <0 on error.  Lets the Python side fail loudly early.
 extern "C" int bm_device_count(void) {
