@@ -71,6 +71,24 @@ def test_conv_forward(h2_mode, H, Cin, M, KS, dil, T, B):
     assert rel_l2(y, ref) < FWD_TOL
 
 
+def test_the_lds_dma_main_loop_kept_for_ab_runs_still_passes():
+    """`BM_CONV_LDSDMA=1` selects the round-2..5 main loop of the wide conv (conv_nn_h2d.hip: weight slabs by LDS-DMA), which
+    ships for interleaved A/B runs; the switch is read once per process, so the conv tests (forward shapes, epilogues,
+    BatchNorm sums, backward) are re-run in a child process under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("BM_CONV_LDSDMA") == "1":
+        pytest.skip("already the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "test_conv_forward or test_conv_epilogues or test_conv_epilogue_batchnorm_statistics or "
+                          "test_conv_backward"],
+                         env=dict(os.environ, BM_CONV_LDSDMA="1"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and " failed" not in out.stdout, out.stdout[-500:]
+
+
 def test_wide_kernel_is_what_runs_for_the_paper_shapes(H, h2_mode):
     for Cin, M, KS, dil, T in [(270, 320, 3, 1, 360), (320, 320, 3, 16, 343), (320, 640, 3, 1, 361),
                                (320, 640, 1, 1, 360), (640, 120, 1, 1, 360), (208, 270, 1, 1, 360),
