@@ -265,7 +265,7 @@ constexpr int R_TOTAL = 3 * R_X + 1;              // three X buffers (two used w
 //      slot) instead of whole 4-VALU pairs + two writes in every other slot; B reads in the free slots of the last groups,
 // 32 = no s_barrier in the loop: three X buffers, a wavefront raises an LDS flag behind its window writes and the readers
 //      of the next chunk check the four flags (a wavefront may run a chunk ahead of its neighbours)
-template <int FLAGS>
+template <int FLAGS, int AUX = 0>
 __global__ __launch_bounds__(256, 1) void probe_rega(const u32x4* __restrict__ wsrc, long wslots, const u32x4* __restrict__ xsrc,
                                                      long xslots, float* __restrict__ out, long long* __restrict__ clk,
                                                      int tiles_per_wg, int nstage, int stagger) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void probe_rega(const u32x4* __restrict__ w
     // A fragments of the stage in slab `SL_` into register set SET_, plane P_, row block MT_ (one 1 KB wave load)
 #define LOAD_A(SET_, P_, MT_, SL_)                                                                            \
     af[SET_][P_][MT_] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(                       \
-        wr, wvoff + (MT_) * 512, ((SL_) * 2 + (P_)) * (2 * R_MPAD * 16), 0));
+        wr, wvoff + (MT_) * 512, ((SL_) * 2 + (P_)) * (2 * R_MPAD * 16), AUX));
     auto body = [&](auto wc) __attribute__((always_inline)) {
     constexpr int W = decltype(wc)::value;
     for (int tile = 0; tile < tiles_per_wg; ++tile) {
@@ -461,11 +461,11 @@ __global__ __launch_bounds__(256, 1) void probe_rega(const u32x4* __restrict__ w
     if (tid == 0) { clk[4 * blockIdx.x] = t_loop; clk[4 * blockIdx.x + 1] = t_tile; clk[4 * blockIdx.x + 2] = wall_clock64() - w_begin; clk[4 * blockIdx.x + 3] = clock64() - c_begin; }
 }
 
-template <int FLAGS>
+template <int FLAGS, int AUX = 0>
 static void run_rega(const u32x4* w, long wslots, const u32x4* x, long xslots, float* out, long long* clk,
                      int tiles_per_wg, int nstage, int stagger) {
     const int lds_bytes = R_TOTAL * 16;
-    CK(hipFuncSetAttribute((const void*)probe_rega<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    CK(hipFuncSetAttribute((const void*)probe_rega<FLAGS, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
@@ -476,7 +476,7 @@ static void run_rega(const u32x4* w, long wslots, const u32x4* x, long xslots, f
     const int reps = re ? atoi(re) : 400;
     for (int rep = 0; rep < reps; ++rep) {
         if (rep == reps / 2) CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(probe_rega<FLAGS>, dim3(256), dim3(256), lds_bytes, 0, w, wslots, x, xslots, out, clk, tiles_per_wg, nstage, stagger);
+        hipLaunchKernelGGL((probe_rega<FLAGS, AUX>), dim3(256), dim3(256), lds_bytes, 0, w, wslots, x, xslots, out, clk, tiles_per_wg, nstage, stagger);
     }
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
@@ -491,8 +491,8 @@ static void run_rega(const u32x4* w, long wslots, const u32x4* x, long xslots, f
         mhz += (double)c[4 * i + 3] / ((double)c[4 * i + 2] / 100.0); wall += (double)c[4 * i + 2] / 100.0;
     }
     tile /= 256; loop /= 256; mhz /= 256; wall /= 256;
-    printf("rega f=%-2d s=%-5d: %7.1f us per launch (in-kernel wall %6.1f us, %4.0f MHz); per tile %7.0f cycles (max %7.0f), main loop "
-           "%7.0f = %5.0f per stage (45 MFMAs = 1440)\n", FLAGS, stagger, best * 1e3, wall, mhz, tile, tmax, loop, loop / nstage);
+    printf("rega f=%-2d aux=%d s=%-5d: %7.1f us per launch (in-kernel wall %6.1f us, %4.0f MHz); per tile %7.0f cycles (max %7.0f), main loop "
+           "%7.0f = %5.0f per stage (45 MFMAs = 1440)\n", FLAGS, AUX, stagger, best * 1e3, wall, mhz, tile, tmax, loop, loop / nstage);
 }
 
 template <bool WINO>
@@ -539,8 +539,15 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         if (!only || only[0] == 'd') run<false>("direct", w, wslots, x, xslots, out, clk, 2, 60);
         if (!only || only[0] == 'w') run<true>("winograd", w, wslots, x, xslots, out, clk, 4, 20);
-        if (!only || only[0] == 'r' || only[0] == 's' || only[0] == 'e') {
-          if (only && only[0] == 'e') {          // where the wall time (= energy, the chip is power-limited) of the kept form goes
+        if (!only || only[0] == 'r' || only[0] == 's' || only[0] == 'e' || only[0] == 'c') {
+          if (only && only[0] == 'c') {          // cache policy of the A loads (aux: 1 = sc0, 2 = nt, 3 = both, 16 = sc1), sustained
+            run_rega<1280, 0>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280, 1>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280, 2>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280, 3>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280, 16>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+            run_rega<1280, 0>(w, wslots, x, xslots, out, clk, 2, 60, 0);
+          } else if (only && only[0] == 'e') {          // where the wall time (= energy, the chip is power-limited) of the kept form goes
             run_rega<1280>(w, wslots, x, xslots, out, clk, 2, 60, 0);
             run_rega<1281>(w, wslots, x, xslots, out, clk, 2, 60, 0);
             run_rega<1282>(w, wslots, x, xslots, out, clk, 2, 60, 0);
