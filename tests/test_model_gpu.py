@@ -1275,6 +1275,39 @@ def test_a_failed_assert_leaves_no_trace_in_the_solver_state():
         assert torch.equal(v, clean_sd[k]), k            # incl. num_batches_tracked and the running statistics
 
 
+def test_a_failed_assert_drops_the_prefetch_that_stood_in_for_a_rejected_batch():
+    """Whole-node negatives: a fully rejected NEXT batch is prefetched as the last good batch (so that the rank issues its
+    candidate gather like the others) -- and between the loss and the deferred assert of a poisoned step the "last good
+    batch" IS the poisoned one.  The rollback must drop that prefetch: a caller that catches the AssertionError and goes
+    on re-trains on the last GOOD batch, with the same loss as if the poisoned batch had never existed; the BatchNorm
+    batch counters come back from a copy."""
+    from brainmagick_amd.solver import Solver
+    from brainmagick_amd.norm import DeviceBatchScaler, ScaleReject
+
+    def run(poison):
+        model, _ = _small_model(merger_dropout=0.0)
+        solver = Solver(model, negatives="node", batch_size=4, scale_reject=ScaleReject(
+            DeviceBatchScaler(torch.zeros(1, 20), torch.ones(1, 20)), limit=20, clip=False))
+        good = [synthetic.make_batch(4, 20, 48, 10, 3, seed=10 + i) for i in range(2)]
+        rejected = synthetic.make_batch(4, 20, 48, 10, 3, seed=5)
+        rejected.meg = rejected.meg * 1e4
+        losses = [float(solver.train_step(good[0]))]
+        counters = [int(m.num_batches_tracked) for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+        if poison:
+            nan = synthetic.make_batch(4, 20, 48, 10, 3, seed=99)
+            nan.features[1, 2, 3] = float("nan")
+            with pytest.raises(AssertionError):
+                solver.train_step(nan, next_batch=rejected)
+            assert solver._last_batch is good[0] and solver._prefetched is None
+            assert counters == [int(m.num_batches_tracked) for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+        losses.append(float(solver.train_step(rejected)))          # re-trains on good[0]
+        losses.append(float(solver.train_step(good[1])))
+        assert all(l == l for l in losses), losses
+        return losses
+
+    assert run(True) == run(False)
+
+
 def test_prefetch_is_by_identity_and_can_be_abandoned():
     """Solver.train_step(batch, next_batch=...) prepares the next batch ahead (device copy, max / finiteness pass, and
     with whole-node negatives the candidate gather); the prepared state is used only if the SAME batch object comes
