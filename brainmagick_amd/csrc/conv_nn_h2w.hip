@@ -32,7 +32,7 @@
 // workgroup meets at one barrier per 16-channel chunk.  B fragments are double-buffered too (read during the
 // previous stage), so a stage is 3 MW NW MFMAs on operands that are all in registers when it starts:
 //     term 0: A.lo x B.hi,  term 1: A.hi x B.lo,  term 2: A.hi x B.hi.
-// What scripts/micro/wino_stage_probe.hip (arm "rega", profiles/r6_rega_probe.txt) measured on the way here:
+// What scripts/micro/wino_stage_probe.hip (arm "rega", profiles/r6_rega_probe_*.txt) measured on the way here:
 //   * the four wavefronts leave a barrier in lockstep; ten 1 KB loads each in consecutive MFMA slots hand the CU's
 //     one texture-address path twice what it takes per slot and the stage costs 1 760 cycles (LDS-DMA: 1 920) --
 //     ONE A load every FOURTH slot: 1 640, and the barrier costs nothing any more (it was absorbing that jitter);
